@@ -1,0 +1,179 @@
+"""The CPU oracle (oracle/difusco_oracle.py) against the golden fixtures generated from the imported
+reference by tests/golden/make_golden.py.  This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import difusco_oracle as O
+
+TOL = 2e-5  # fp32 op-for-op restatement on the same CPU backend; observed differences are ~1e-6
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def weights(golden_dir):
+    z = load(golden_dir, "weights_h64_l2.npz")
+    cat = {k: torch.from_numpy(z[k]) for k in z.files if k != "provenance" and not k.startswith("gaussian_")}
+    gau = dict(cat)
+    for k in z.files:
+        if k.startswith("gaussian_"):
+            gau[k[len("gaussian_"):]] = torch.from_numpy(z[k])
+    return cat, gau
+
+
+def test_tables_and_schedule(golden_dir):
+    z = load(golden_dir, "schedules.npz")
+    assert str(z["provenance"]).startswith("reference")
+    for kind in ("linear", "cosine"):
+        c, g = O.CategoricalTables(1000, kind), O.GaussianTables(1000, kind)
+        np.testing.assert_array_equal(c.Q_bar, z[f"Q_bar_{kind}"])
+        np.testing.assert_array_equal(g.alphabar, z[f"alphabar_{kind}"])
+        for S in (50, 7, 1000):
+            got = np.array([O.inference_schedule(kind, 1000, S, i) for i in range(S)])
+            np.testing.assert_array_equal(got, z[f"sched_{kind}_{S}"])
+    t = torch.from_numpy(z["temb_t"])
+    np.testing.assert_array_equal(O.timestep_embedding(t, 64).numpy(), z["temb_64"])
+    np.testing.assert_array_equal(O.timestep_embedding(t, 256).numpy(), z["temb_256"])
+    # the published configuration: 50 cosine steps start at (1000, 969) and end at (1, 0)
+    s = z["sched_cosine_50"]
+    assert tuple(s[0]) == (1000, 969) and tuple(s[-1]) == (1, 0)
+
+
+def test_posteriors(golden_dir):
+    z = load(golden_dir, "posteriors.npz")
+    tab = O.CategoricalTables(1000, "linear")
+    for i in range(6):
+        t, tt = (int(v) for v in z[f"cat{i}_t"])
+        tt = None if tt < 0 else tt
+        x0, xt = torch.from_numpy(z[f"cat{i}_x0"]), torch.from_numpy(z[f"cat{i}_xt"])
+        u = torch.from_numpy(z[f"cat{i}_uniform"]) if f"cat{i}_uniform" in z.files else None
+        out, prob = O.categorical_posterior(tab, t, tt, x0, xt, True, uniform=u)
+        if u is not None:
+            np.testing.assert_allclose(prob.numpy(), z[f"cat{i}_prob"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(out.numpy(), z[f"cat{i}_out"], rtol=0, atol=1e-7)
+    gt = O.GaussianTables(1000, "linear")
+    for i in range(5):
+        t, tt = (int(v) for v in z[f"gau{i}_t"])
+        trick = "ddim" if int(z[f"gau{i}_trick"]) else None
+        noise = torch.from_numpy(z[f"gau{i}_noise"]) if f"gau{i}_noise" in z.files else None
+        out = O.gaussian_posterior(gt, t, tt, torch.from_numpy(z[f"gau{i}_pred"]),
+                                   torch.from_numpy(z[f"gau{i}_xt"]), trick, noise)
+        np.testing.assert_allclose(out.numpy(), z[f"gau{i}_out"], rtol=0, atol=1e-6)
+
+
+def test_dense_tsp(golden_dir, weights):
+    z = load(golden_dir, "tsp_dense_h64_l2.npz")
+    assert "none executed" in str(z["provenance"])
+    cat, gau = weights
+    pts = torch.from_numpy(z["points"])
+    tab, gt = O.CategoricalTables(), O.GaussianTables()
+    for i in range(3):
+        t, tt = (int(v) for v in z[f"cat{i}_t"])
+        xt = torch.from_numpy(z[f"cat{i}_xt"])
+        u = torch.from_numpy(z[f"cat{i}_uniform"]) if f"cat{i}_uniform" in z.files else None
+        out, logits, prob = O.tsp_categorical_denoise_step(cat, tab, pts, xt, t, None, tt, uniform=u, return_aux=True)
+        np.testing.assert_allclose(logits.numpy(), z[f"cat{i}_logits"], rtol=0, atol=TOL)
+        if u is not None:
+            ref_p = z[f"cat{i}_prob"]
+            np.testing.assert_allclose(prob.numpy(), ref_p, rtol=0, atol=TOL)
+            safe = np.abs(z[f"cat{i}_uniform"] - ref_p) > 1e-5
+            np.testing.assert_array_equal(out.numpy()[safe], z[f"cat{i}_out"][safe])
+        else:
+            np.testing.assert_allclose(out.numpy(), z[f"cat{i}_out"], rtol=0, atol=TOL)
+    for i in range(2):
+        t, tt = (int(v) for v in z[f"gau{i}_t"])
+        noise = torch.from_numpy(z[f"gau{i}_noise"]) if f"gau{i}_noise" in z.files else None
+        out, pred = O.tsp_gaussian_denoise_step(gau, gt, pts, torch.from_numpy(z[f"gau{i}_xt"]), t, None, tt,
+                                                noise=noise, return_aux=True)
+        np.testing.assert_allclose(pred.numpy(), z[f"gau{i}_pred"].squeeze(1), rtol=0, atol=TOL)
+        np.testing.assert_allclose(out.numpy(), z[f"gau{i}_out"], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("G", [1, 3])
+@pytest.mark.parametrize("v_on_edges", [True, False])
+def test_sparse_tsp(golden_dir, weights, G, v_on_edges):
+    z = load(golden_dir, f"tsp_sparse_h64_l2_g{G}.npz")
+    assert "substitute aggregation" in str(z["provenance"])
+    cat, gau = weights
+    pts, ei = torch.from_numpy(z["points"]), torch.from_numpy(z["edge_index"])
+    tab, gt = O.CategoricalTables(), O.GaussianTables()
+    for i in range(4):
+        t, tt = (int(v) for v in z[f"cat{i}_t"])
+        xt = torch.from_numpy(z[f"cat{i}_xt"])
+        u = torch.from_numpy(z[f"cat{i}_uniform"]) if f"cat{i}_uniform" in z.files else None
+        out, logits, prob = O.tsp_categorical_denoise_step(cat, tab, pts, xt, t, ei, tt, uniform=u,
+                                                           v_on_edges=v_on_edges, return_aux=True)
+        np.testing.assert_allclose(logits.numpy(), z[f"cat{i}_logits"], rtol=0, atol=TOL)
+        if u is not None:
+            ref_p = z[f"cat{i}_prob"]
+            np.testing.assert_allclose(prob.numpy(), ref_p, rtol=0, atol=TOL)
+            safe = (np.abs(z[f"cat{i}_uniform"] - ref_p) > 1e-5).reshape(-1)
+            np.testing.assert_array_equal(out.numpy()[safe], z[f"cat{i}_out"][safe])
+        else:
+            np.testing.assert_allclose(out.numpy(), z[f"cat{i}_out"], rtol=0, atol=TOL)
+    for i in range(2):
+        t, tt = (int(v) for v in z[f"gau{i}_t"])
+        noise = torch.from_numpy(z[f"gau{i}_noise"]) if f"gau{i}_noise" in z.files else None
+        out, pred = O.tsp_gaussian_denoise_step(gau, gt, pts, torch.from_numpy(z[f"gau{i}_xt"]), t, ei, tt,
+                                                noise=noise, v_on_edges=v_on_edges, return_aux=True)
+        np.testing.assert_allclose(pred.numpy(), z[f"gau{i}_pred"].squeeze(1), rtol=0, atol=TOL)
+        np.testing.assert_allclose(out.numpy(), z[f"gau{i}_out"], rtol=0, atol=TOL)
+
+
+def test_groupnorm_couples_the_batch(golden_dir, weights):
+    """the sparse head normalises over ALL edges of the call - the G=3 fixture must not
+    equal three independent G=1 calls, and the oracle must reproduce exactly that coupling."""
+    z1, z3 = load(golden_dir, "tsp_sparse_h64_l2_g1.npz"), load(golden_dir, "tsp_sparse_h64_l2_g3.npz")
+    cat, _ = weights
+    E1 = z1["edge_index"].shape[1]
+    xt3 = torch.from_numpy(z3["cat0_xt"])
+    one = O.encoder_sparse_edge(cat, torch.from_numpy(z1["points"]), xt3[:E1].float(), torch.tensor([1000.0]),
+                                torch.from_numpy(z1["edge_index"]))
+    assert np.abs(one.numpy() - z3["cat0_logits"][:E1]).max() > 1e-3
+
+
+def test_sparse_mis(golden_dir, weights):
+    z = load(golden_dir, "mis_sparse_h64_l2.npz")
+    cat, gau = weights
+    ei = torch.from_numpy(z["edge_index"])
+    tab, gt = O.CategoricalTables(), O.GaussianTables()
+    for i in range(3):
+        t, tt = (int(v) for v in z[f"cat{i}_t"])
+        xt = torch.from_numpy(z[f"cat{i}_xt"])
+        u = torch.from_numpy(z[f"cat{i}_uniform"]) if f"cat{i}_uniform" in z.files else None
+        out, logits, prob = O.mis_categorical_denoise_step(cat, tab, xt, t, ei, tt, uniform=u, return_aux=True)
+        np.testing.assert_allclose(logits.numpy(), z[f"cat{i}_logits"], rtol=0, atol=TOL)
+        if u is not None:
+            ref_p = z[f"cat{i}_prob"]
+            np.testing.assert_allclose(prob.numpy(), ref_p, rtol=0, atol=TOL)
+            safe = (np.abs(z[f"cat{i}_uniform"] - ref_p) > 1e-5).reshape(-1)
+            np.testing.assert_array_equal(out.numpy()[safe], z[f"cat{i}_out"][safe])
+        else:
+            np.testing.assert_allclose(out.numpy(), z[f"cat{i}_out"], rtol=0, atol=TOL)
+    for i in range(2):
+        t, tt = (int(v) for v in z[f"gau{i}_t"])
+        noise = torch.from_numpy(z[f"gau{i}_noise"]) if f"gau{i}_noise" in z.files else None
+        out, pred = O.mis_gaussian_denoise_step(gau, gt, torch.from_numpy(z[f"gau{i}_xt"]), t, ei, tt,
+                                                noise=noise, return_aux=True)
+        np.testing.assert_allclose(pred.numpy(), z[f"gau{i}_pred"].squeeze(1), rtol=0, atol=TOL)
+        np.testing.assert_allclose(out.numpy(), z[f"gau{i}_out"], rtol=0, atol=TOL)
+
+
+def test_duplicate_edge_index_matches_fixture(golden_dir):
+    z1, z3 = load(golden_dir, "tsp_sparse_h64_l2_g1.npz"), load(golden_dir, "tsp_sparse_h64_l2_g3.npz")
+    got = O.duplicate_edge_index(torch.from_numpy(z1["edge_index"]), int(z1["nodes_per_graph"]), 3)
+    np.testing.assert_array_equal(got.numpy(), z3["edge_index"])
+
+
+def test_knn_graph_layout():
+    pts, ei = O.tsp_instance(64, 8, seed=3)
+    assert ei.shape == (2, 64 * 8)
+    assert (ei[0] == np.repeat(np.arange(64), 8)).all()
+    assert (ei[1].reshape(64, 8)[:, 0] == np.arange(64)).all()  # self is the nearest neighbour
+    d = np.linalg.norm(pts[ei[0]] - pts[ei[1]], axis=1).reshape(64, 8)
+    assert (np.diff(d, axis=1) >= 0).all()
