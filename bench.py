@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py - denoising-step throughput of the MI355X-native DIFUSCO sampler.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): graph-steps/s = graphs in flight x denoise steps / wall time, on the headline
+configuration TSP-1000 k-NN-sparse (K=100), categorical diffusion, H=256, 12 layers, fp32,
+8 graphs per GPU (configs[2]: batch 64 sharded over 8 GPUs -> weak scaling).  One "step" = one
+reverse-diffusion step (12-layer GNN forward + categorical posterior + Bernoulli draw) over the
+rank's whole batch; inputs are resident in HBM when the timed region starts.  Synthetic data:
+uniform random points, k-NN graph incl. self, random-init weights of the reference architecture with
+per_layer_out re-randomised.  One JSON line on stdout (rank 0).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, LAYERS = 256, 12
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0              # HBM3E spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(n_nodes, k, steps, params):
+    """The CPU oracle (port of the reference op sequence, incl. V applied on E gathered rows) on a bounded
+    sample: ONE graph of the same workload, 1 warm-up + `steps` timed denoise steps.  This leg is the only
+    place where bench.py touches oracle/."""
+    from oracle import difusco_oracle as O
+    from difusco_amd.synthetic import tsp_instance
+    pts, ei = tsp_instance(n_nodes, k, seed=1000)
+    pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
+    tab = O.CategoricalTables()
+    g = torch.Generator().manual_seed(0)
+    xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
+    with torch.no_grad():
+        xt = O.tsp_categorical_denoise_step(params, tab, pts, xt, 1000, ei, 969, generator=g)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            t1, t2 = O.inference_schedule("cosine", 1000, 50, i + 1)
+            xt = O.tsp_categorical_denoise_step(params, tab, pts, xt, t1, ei, t2, generator=g)
+        dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "graph-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 graph TSP-{n_nodes} K={k} H={H} L={LAYERS} fp32, 1 warm-up + {steps} timed steps "
+                      f"of the CPU oracle ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nodes", type=int, default=1000)
+    ap.add_argument("--knn", type=int, default=100)
+    ap.add_argument("--graphs-per-gpu", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (0 = skip cpu_baseline)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the in-library HIP-event brackets")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+    from difusco_amd import _lib
+    from difusco_amd.dist import GN_STATS_MODE, engine_from_broadcast, shard_range
+    from difusco_amd.engine import DenoiseEngine
+    from difusco_amd.models import TSPModel
+    from difusco_amd.schedules import InferenceSchedule
+    from difusco_amd.synthetic import random_state_dict, tsp_batch
+
+    # frozen weights: rank 0 creates, RCCL broadcast of the packed blob over xGMI
+    params = random_state_dict(H, LAYERS, 2, seed=20240926) if rank == 0 or world == 1 else None
+    if world > 1:
+        engine = engine_from_broadcast(params, device, src=0)
+    else:
+        engine = DenoiseEngine(params, device=device)
+    margs = dict(diffusion_type="categorical", diffusion_schedule="linear", diffusion_steps=1000,
+                 inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn,
+                 n_layers=LAYERS, hidden_dim=H)
+    model = TSPModel(margs, engine=engine, seed=1234 + rank)
+
+    # this rank's shard of the global batch (weak scaling: graphs_per_gpu fixed)
+    G_total = args.graphs_per_gpu * world
+    lo, hi = shard_range(G_total, rank, world)
+    points, edge_index = tsp_batch(args.nodes, args.knn, range(lo, hi), device)
+    G_local = hi - lo
+    E_local = edge_index.shape[1]
+    gen = torch.Generator().manual_seed(77 + rank)
+    xt = (torch.randn(E_local, generator=gen) > 0).float().to(device)
+    sched = InferenceSchedule("cosine", T=1000, inference_T=50)
+
+    def one_step(i, xt):
+        t1, t2 = sched(i % 49)                                  # never the final (t2 = 0) step: keeps xt binary
+        return model.categorical_denoise_step(points, xt, np.array([t1]), device, edge_index, target_t=np.array([t2]))
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        xt = one_step(i, xt)
+    NCAT = 5
+    if not args.no_profile:
+        _lib.check(_lib.lib().difusco_profile_enable(1, args.steps * (4 * LAYERS + 16)))
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        xt = one_step(args.warmup + i, xt)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    prof = None
+    if not args.no_profile:
+        ms = (ctypes.c_double * NCAT)()
+        cnt = (ctypes.c_int64 * NCAT)()
+        _lib.check(_lib.lib().difusco_profile_collect(ms, cnt, NCAT))
+        _lib.lib().difusco_profile_enable(0, 0)
+        prof = {"ms": list(ms), "launches": list(cnt)}
+
+    if rank == 0:
+        value = G_total * args.steps / dt
+        out = {
+            "metric": "denoising steps/sec (graphs x steps / s), TSP-1000 k-NN sparse categorical",
+            "value": value, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TSP-{args.nodes} k-NN K={args.knn} sparse categorical, cosine 50-step schedule, "
+                                   f"{args.graphs_per_gpu} graphs per GPU (global batch {G_total}), H={H}, {LAYERS} layers",
+                       "graphs_per_gpu": args.graphs_per_gpu, "global_batch": G_total, "nodes": args.nodes,
+                       "knn": args.knn, "edges_per_graph": args.nodes * args.knn, "gn_stats": GN_STATS_MODE,
+                       "rng": "on-device philox", "weights_seed": 20240926},
+        }
+        if prof is not None and prof["launches"][0] > 0:
+            n_lin = prof["launches"][0]
+            avg_s = prof["ms"][0] / n_lin * 1e-3
+            flops = 2.0 * E_local * H * H                       # one E-row linear: [E,H] x [H,H]^T
+            achieved = flops / avg_s / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "kernel": "linear_rows_kernel<256,256,16> (E-row linear, fp32 MFMA)",
+                               "avg_launch_ms": avg_s * 1e3, "launches": n_lin,
+                               "algorithmic_flops_per_launch": flops,
+                               "algorithmic_bytes_per_launch": 2.0 * E_local * H * 4}
+            n_g = max(prof["launches"][2], 1)
+            g_s = prof["ms"][2] / n_g * 1e-3
+            gate_bytes = 2.0 * E_local * H * 4                  # read C e, write act (node tables are L2/MALL traffic)
+            out["kernels"] = {
+                "edge_linear": {"ms_total": prof["ms"][0], "launches": prof["launches"][0]},
+                "node_linear": {"ms_total": prof["ms"][1], "launches": prof["launches"][1]},
+                "edge_gate_aggregate": {"ms_total": prof["ms"][2], "launches": prof["launches"][2],
+                                        "achieved_GBs": gate_bytes / g_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                                        "frac": gate_bytes / g_s / 1e9 / PEAK_HBM_GBS, "bound": "hbm",
+                                        "algorithmic_bytes_per_launch": gate_bytes},
+                "head": {"ms_total": prof["ms"][3], "launches": prof["launches"][3]},
+                "embed_misc": {"ms_total": prof["ms"][4], "launches": prof["launches"][4]},
+                "sum_ms_per_step": sum(prof["ms"]) / args.steps,
+            }
+        if world == 1 and args.cpu_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(args.nodes, args.knn, args.cpu_steps, params)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

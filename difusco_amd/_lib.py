@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI in include/difusco_hip.h.  No fallback: if the HIP library is missing
+the import of anything that computes fails loudly (the product path never routes through a CPU path)."""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+ABI_VERSION = 1
+TASK_TSP, TASK_MIS = 0, 1
+CATEGORICAL, GAUSSIAN = 0, 1
+RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
+
+# indices into difusco_weights_layout() (mirrors the enums of include/difusco_hip.h)
+W_GLOBAL = ["node_embed.weight", "node_embed.bias", "edge_embed.weight", "edge_embed.bias",
+            "time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias",
+            "out.0.weight", "out.0.bias", "out.2.weight", "out.2.bias",
+            "@time_freqs", "@dimt_pos", "@dimt_scalar"]
+W_LAYER = ["@node4.weight", "@node4.bias", "layers.{l}.C.weight", "layers.{l}.C.bias",
+           "layers.{l}.norm_h.weight", "layers.{l}.norm_h.bias", "layers.{l}.norm_e.weight", "layers.{l}.norm_e.bias",
+           "time_embed_layers.{l}.1.weight", "time_embed_layers.{l}.1.bias",
+           "per_layer_out.{l}.0.weight", "per_layer_out.{l}.0.bias",
+           "per_layer_out.{l}.2.weight", "per_layer_out.{l}.2.bias"]
+
+
+class StepArgs(ctypes.Structure):
+    """difusco_step_args (include/difusco_hip.h)."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("abi_version", ctypes.c_uint32),
+        ("hidden", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+        ("out_channels", ctypes.c_int32), ("task", ctypes.c_int32),
+        ("weights", ctypes.c_void_p),
+        ("n_nodes", ctypes.c_int32), ("n_edges", ctypes.c_int32),
+        ("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("perm", ctypes.c_void_p),
+        ("n_segments", ctypes.c_int32), ("seg_ptr", ctypes.c_void_p),
+        ("points", ctypes.c_void_p), ("xt", ctypes.c_void_p),
+        ("t", ctypes.c_float), ("xt_is_binary", ctypes.c_int32),
+        ("diffusion", ctypes.c_int32), ("post", ctypes.c_float * 8),
+        ("rand_mode", ctypes.c_int32), ("rand", ctypes.c_void_p),
+        ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
+        ("xt_out", ctypes.c_void_p), ("pred_out", ctypes.c_void_p), ("prob_out", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("stream", ctypes.c_void_p),
+    ]
+
+
+class DifuscoHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library (loads on first use; raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DifuscoHipError(
+            f"{LIB_PATH} is missing: build it with `python -m difusco_amd.build` "
+            "(there is deliberately no CPU / PyTorch fallback)")
+    L = ctypes.CDLL(LIB_PATH)
+    i32, i64, vp, f32p = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
+    L.difusco_abi_version.restype = ctypes.c_int
+    L.difusco_last_error.restype = ctypes.c_char_p
+    L.difusco_weights_layout.argtypes = [i32, i32, i32, ctypes.POINTER(i64), i32, ctypes.POINTER(i64)]
+    L.difusco_csr_from_coo_host.argtypes = [vp, i64, i64, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int)]
+    L.difusco_workspace_bytes.restype = ctypes.c_size_t
+    L.difusco_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.difusco_denoise_step.argtypes = [ctypes.POINTER(StepArgs)]
+    L.difusco_linear_rows.argtypes = [f32p, f32p, f32p, f32p, f32p, i64, i32, i32, i64, vp]
+    L.difusco_edge_gate_aggregate.argtypes = [i32, i32, vp, vp, f32p, f32p, f32p] + [f32p] * 7 + [i32, vp]
+    L.difusco_categorical_posterior.argtypes = [f32p, f32p, ctypes.POINTER(ctypes.c_float), i32, f32p,
+                                                ctypes.c_uint64, ctypes.c_uint64, f32p, f32p, i64, vp]
+    L.difusco_gaussian_posterior.argtypes = [f32p, f32p, ctypes.POINTER(ctypes.c_float), i32, f32p,
+                                             ctypes.c_uint64, ctypes.c_uint64, f32p, i64, vp]
+    if L.difusco_abi_version() != ABI_VERSION:
+        raise DifuscoHipError(f"ABI version mismatch: library {L.difusco_abi_version()} != binding {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def check(code: int):
+    if code < 0:
+        raise DifuscoHipError(f"libdifusco_hip error {code}: {lib().difusco_last_error().decode()}")
+    return code
+
+
+def weights_layout(hidden: int, n_layers: int, out_channels: int):
+    """(offsets, total_floats) of the packed weight blob - the C library is the source of truth."""
+    n = len(W_GLOBAL) + n_layers * len(W_LAYER)
+    off = (ctypes.c_int64 * n)()
+    tot = ctypes.c_int64()
+    got = check(lib().difusco_weights_layout(hidden, n_layers, out_channels, off, n, ctypes.byref(tot)))
+    if got != n:
+        raise DifuscoHipError(f"weight layout has {got} entries, binding expects {n}")
+    return list(off), tot.value

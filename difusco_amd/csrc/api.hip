@@ -1,0 +1,354 @@
+// C ABI of libdifusco_hip.so (declared in include/difusco_hip.h) and the step driver that strings the
+// gfx950 kernels into one reverse-diffusion step.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/difusco_hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(DIFUSCO_EHIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+  } while (0)
+
+constexpr int64_t kAlignFloats = 64;  // every packed tensor starts on a 256-byte boundary
+
+int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+struct Layout {
+  std::vector<int64_t> off;
+  int64_t total = 0;
+  int64_t layer_stride = 0;  // floats between the same tensor of consecutive layers
+};
+
+bool hidden_ok(int h) { return h == 64 || h == 128 || h == 256; }
+
+Layout make_layout(int H, int L, int C) {
+  Layout lo;
+  const int64_t T2 = H / 2;
+  int64_t cur = 0;
+  auto push = [&](int64_t n) {
+    lo.off.push_back(cur);
+    cur = align_up(cur + n, kAlignFloats);
+  };
+  push((int64_t)H * H); push(H);          // node_embed
+  push((int64_t)H * H); push(H);          // edge_embed
+  push(T2 * H); push(T2);                 // time_embed.0
+  push(T2 * T2); push(T2);                // time_embed.2
+  push(H); push(H);                       // out.0 (GroupNorm affine)
+  push((int64_t)C * H); push(C);          // out.2 (1x1 conv)
+  push(T2); push(T2); push(H);            // freqs, dimt_pos, dimt_scalar
+  const int64_t layer0 = cur;
+  for (int l = 0; l < L; ++l) {
+    push((int64_t)4 * H * H); push((int64_t)4 * H);  // node4 = U|V|A|B
+    push((int64_t)H * H); push(H);                    // C
+    push(H); push(H); push(H); push(H);               // norm_h, norm_e
+    push((int64_t)H * T2); push(H);                   // time layer
+    push(H); push(H);                                 // per_layer_out LN
+    push((int64_t)H * H); push(H);                    // per_layer_out linear
+    if (l == 0) lo.layer_stride = cur - layer0;
+  }
+  lo.total = cur;
+  return lo;
+}
+
+struct Workspace {
+  float *h, *node4, *e, *tmp, *tbias, *table_in, *table, *stats;
+  double* partial;
+  size_t bytes;
+};
+
+Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk) {
+  Workspace w;
+  size_t cur = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = cur;
+    cur = (cur + bytes + 255) / 256 * 256;
+    return base ? (void*)((char*)base + at) : (void*)nullptr;
+  };
+  w.h = (float*)take(sizeof(float) * N * H);
+  w.node4 = (float*)take(sizeof(float) * N * 4 * H);
+  w.e = (float*)take(sizeof(float) * E * H);
+  w.tmp = (float*)take(sizeof(float) * (E > 2 ? E : 2) * H);
+  w.tbias = (float*)take(sizeof(float) * L * H);
+  w.table_in = (float*)take(sizeof(float) * 2 * H);
+  w.table = (float*)take(sizeof(float) * 2 * H);
+  w.stats = (float*)take(sizeof(float) * S * 64);
+  w.partial = (double*)take(sizeof(double) * (size_t)S * nblk * 64);
+  w.bytes = cur;
+  return w;
+}
+
+
+// ---- optional in-library profiler: HIP events around every kernel launch, per category ----------
+// (bench.py needs the average duration of the dominant kernel measured on the launch stream inside
+// the timed region; the launches happen inside difusco_denoise_step, so the brackets live here.)
+enum { PROF_LINEAR_EDGE = 0, PROF_LINEAR_NODE, PROF_GATE, PROF_HEAD, PROF_EMBED, PROF_NCAT };
+struct Profiler {
+  bool on = false;
+  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<int> cat;
+  size_t used = 0;              // pairs in use
+} g_prof;
+
+struct ProfScope {
+  hipStream_t st;
+  bool active;
+  size_t slot;
+  ProfScope(int category, hipStream_t s) : st(s), active(false), slot(0) {
+    if (!g_prof.on || g_prof.used * 2 + 2 > g_prof.ev.size()) return;
+    slot = g_prof.used++;
+    g_prof.cat[slot] = category;
+    active = hipEventRecord(g_prof.ev[2 * slot], st) == hipSuccess;
+  }
+  ~ProfScope() {
+    if (active) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int difusco_abi_version(void) { return DIFUSCO_ABI_VERSION; }
+
+const char* difusco_last_error(void) { return g_err; }
+
+int difusco_weights_layout(int hidden, int n_layers, int out_channels, int64_t* offsets, int max_entries,
+                           int64_t* total_floats) {
+  if (!hidden_ok(hidden)) return fail(DIFUSCO_EINVAL, "hidden must be 64, 128 or 256 (got %d)", hidden);
+  if (n_layers < 1 || (out_channels != 1 && out_channels != 2))
+    return fail(DIFUSCO_EINVAL, "n_layers >= 1 and out_channels in {1,2} required");
+  Layout lo = make_layout(hidden, n_layers, out_channels);
+  const int n = (int)lo.off.size();
+  if (offsets) {
+    if (max_entries < n) return fail(DIFUSCO_EINVAL, "offset array too small: need %d", n);
+    std::memcpy(offsets, lo.off.data(), sizeof(int64_t) * n);
+  }
+  if (total_floats) *total_floats = lo.total;
+  return n;
+}
+
+int difusco_csr_from_coo_host(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, int32_t* rowptr,
+                              int32_t* col, int32_t* row, int32_t* perm, int* identity) {
+  if (!edge_index || !rowptr || !col || !row || !perm) return fail(DIFUSCO_EINVAL, "null pointer");
+  if (n_edges < 0 || n_nodes < 0 || n_edges > INT32_MAX || n_nodes >= INT32_MAX)
+    return fail(DIFUSCO_EINVAL, "sizes out of int32 range");
+  const int64_t* r = edge_index;
+  const int64_t* c = edge_index + n_edges;
+  for (int64_t i = 0; i <= n_nodes; ++i) rowptr[i] = 0;
+  for (int64_t k = 0; k < n_edges; ++k) {
+    if (r[k] < 0 || r[k] >= n_nodes || c[k] < 0 || c[k] >= n_nodes)
+      return fail(DIFUSCO_EINVAL, "edge %lld = (%lld,%lld) out of range [0,%lld)", (long long)k, (long long)r[k],
+                  (long long)c[k], (long long)n_nodes);
+    rowptr[r[k] + 1]++;
+  }
+  for (int64_t i = 0; i < n_nodes; ++i) rowptr[i + 1] += rowptr[i];
+  std::vector<int32_t> fill(rowptr, rowptr + n_nodes);
+  int ident = 1;
+  for (int64_t k = 0; k < n_edges; ++k) {  // stable counting sort by centre node
+    const int32_t s = fill[r[k]]++;
+    col[s] = (int32_t)c[k];
+    row[s] = (int32_t)r[k];
+    perm[s] = (int32_t)k;
+    if (s != k) ident = 0;
+  }
+  if (identity) *identity = ident;
+  return DIFUSCO_OK;
+}
+
+size_t difusco_workspace_bytes(int hidden, int n_layers, int n_nodes, int n_edges, int n_segments) {
+  if (!hidden_ok(hidden) || n_layers < 1 || n_nodes < 0 || n_edges < 0 || n_segments < 1) return 0;
+  const long long rows = n_edges > n_nodes ? n_edges : n_nodes;
+  return carve(nullptr, hidden, n_layers, n_nodes, n_edges, n_segments, difusco::gn_blocks_for(rows)).bytes;
+}
+
+int difusco_denoise_step(const difusco_step_args* a) {
+  using namespace difusco;
+  if (!a) return fail(DIFUSCO_EINVAL, "null args");
+  if (a->struct_size != sizeof(difusco_step_args) || a->abi_version != DIFUSCO_ABI_VERSION)
+    return fail(DIFUSCO_EINVAL, "ABI mismatch: struct_size %u (want %zu), abi %u (want %d)", a->struct_size,
+                sizeof(difusco_step_args), a->abi_version, DIFUSCO_ABI_VERSION);
+  const int H = a->hidden, L = a->n_layers, C = a->out_channels;
+  if (!hidden_ok(H)) return fail(DIFUSCO_EINVAL, "hidden must be 64, 128 or 256 (got %d)", H);
+  if (L < 1) return fail(DIFUSCO_EINVAL, "n_layers must be >= 1");
+  if (a->task != DIFUSCO_TASK_TSP && a->task != DIFUSCO_TASK_MIS) return fail(DIFUSCO_EINVAL, "unknown task %d", a->task);
+  if (a->diffusion != DIFUSCO_CATEGORICAL && a->diffusion != DIFUSCO_GAUSSIAN)
+    return fail(DIFUSCO_EINVAL, "unknown diffusion %d", a->diffusion);
+  if (C != (a->diffusion == DIFUSCO_CATEGORICAL ? 2 : 1))
+    return fail(DIFUSCO_EINVAL, "out_channels %d does not match diffusion type", C);
+  const int64_t N = a->n_nodes, E = a->n_edges;
+  if (N <= 0 || E < 0) return fail(DIFUSCO_EINVAL, "n_nodes must be > 0, n_edges >= 0");
+  if (!a->weights || !a->rowptr || (E > 0 && !a->col) || !a->xt || !a->xt_out || !a->workspace)
+    return fail(DIFUSCO_EINVAL, "null device pointer (weights/rowptr/col/xt/xt_out/workspace)");
+  if (a->task == DIFUSCO_TASK_TSP && !a->points) return fail(DIFUSCO_EINVAL, "TSP needs points");
+  if (a->task == DIFUSCO_TASK_TSP && E == 0) return fail(DIFUSCO_EINVAL, "TSP needs edges");
+  if (a->n_segments < 1 || (a->n_segments > 1 && !a->seg_ptr))
+    return fail(DIFUSCO_EINVAL, "n_segments >= 1, seg_ptr required when > 1");
+  if (a->rand_mode == DIFUSCO_RAND_INJECTED && !a->rand) return fail(DIFUSCO_EINVAL, "injected randomness needs rand");
+  if (a->rand_mode < 0 || a->rand_mode > 2) return fail(DIFUSCO_EINVAL, "unknown rand_mode %d", a->rand_mode);
+  const bool needs_draw = a->post[4] != 0.0f;
+  if (needs_draw && a->rand_mode == DIFUSCO_RAND_NONE)
+    return fail(DIFUSCO_EINVAL, "this step draws random numbers: rand_mode must not be NONE");
+
+  const bool tsp = a->task == DIFUSCO_TASK_TSP;
+  const int64_t out_rows = tsp ? E : N;
+  const int nblk = gn_blocks_for(E > N ? E : N);
+  Workspace ws = carve(a->workspace, H, L, N, E, a->n_segments, nblk);
+  if (ws.bytes > a->workspace_bytes)
+    return fail(DIFUSCO_EWORKSPACE, "workspace too small: %zu < %zu", a->workspace_bytes, ws.bytes);
+
+  const Layout lo = make_layout(H, L, C);
+  const float* W = a->weights;
+  auto G = [&](int id) { return W + lo.off[id]; };
+  auto LW = [&](int l, int id) { return W + lo.off[DIFUSCO_W_GLOBAL_COUNT + l * DIFUSCO_WL_COUNT + id]; };
+  hipStream_t st = (hipStream_t)a->stream;
+
+  // PROF(category, call): HIP_TRY(call), bracketed by a pair of HIP events on `st` when profiling is on
+#define PROF(cat, call)      \
+  {                          \
+    ProfScope ps_(cat, st);  \
+    HIP_TRY(call);           \
+  }
+
+  // per-layer time bias rows: time_layer_l(time_embed(timestep_embedding(t)))   [L,H]
+  PROF(PROF_EMBED, launch_time_bias(a->t, H, L, G(DIFUSCO_W_TIME_FREQS), G(DIFUSCO_W_TIME0_W), G(DIFUSCO_W_TIME0_B),
+                                    G(DIFUSCO_W_TIME2_W), G(DIFUSCO_W_TIME2_B), LW(0, 0), lo.layer_stride,
+                                    lo.off[DIFUSCO_W_GLOBAL_COUNT + DIFUSCO_WL_TIME_W] - lo.off[DIFUSCO_W_GLOBAL_COUNT],
+                                    lo.off[DIFUSCO_W_GLOBAL_COUNT + DIFUSCO_WL_TIME_B] - lo.off[DIFUSCO_W_GLOBAL_COUNT],
+                                    ws.tbias, st))
+
+  // input embeddings (gnn_encoder.py:394-395 TSP, :405-407 MIS).  node4 doubles as scratch for the
+  // sinusoidal node features before the first layer overwrites it.
+  if (tsp) {
+    PROF(PROF_EMBED, launch_pos_embed(a->points, G(DIFUSCO_W_DIMT_POS), (int)N, H, ws.node4, st))
+    PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
+                                       H, H, H, st))
+    if (a->xt_is_binary) {
+      PROF(PROF_EMBED, launch_scalar_embed(nullptr, nullptr, G(DIFUSCO_W_DIMT_SCALAR), 2, H, ws.table_in, st))
+      PROF(PROF_EMBED, linear_rows(ws.table_in, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.table,
+                                   2, H, H, H, st))
+      PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, ws.table, E, H, ws.e, st))
+    } else {
+      PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
+      PROF(PROF_LINEAR_EDGE, linear_rows(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.e, E,
+                                         H, H, H, st))
+    }
+  } else {
+    PROF(PROF_EMBED, launch_scalar_embed(a->xt, nullptr, G(DIFUSCO_W_DIMT_SCALAR), N, H, ws.node4, st))
+    PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
+                                       H, H, H, st))
+    if (E > 0) PROF(PROF_EMBED, hipMemsetAsync(ws.e, 0, sizeof(float) * E * H, st))
+  }
+
+  // the GNN layers (gnn_encoder.py:425-449)
+  for (int l = 0; l < L; ++l) {
+    PROF(PROF_LINEAR_NODE, linear_rows(ws.h, LW(l, DIFUSCO_WL_NODE4_W), LW(l, DIFUSCO_WL_NODE4_B), nullptr, ws.node4, N,
+                                       H, 4 * H, 4 * H, st))
+    PROF(PROF_LINEAR_EDGE, linear_rows(ws.e, LW(l, DIFUSCO_WL_C_W), LW(l, DIFUSCO_WL_C_B), nullptr, ws.tmp, E, H, H, H, st))
+    PROF(PROF_GATE, launch_edge_gate_aggregate(H, (int)N, a->rowptr, a->col, ws.node4, ws.tmp, ws.h,
+                                               LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
+                                               LW(l, DIFUSCO_WL_NORM_E_W), LW(l, DIFUSCO_WL_NORM_E_B),
+                                               LW(l, DIFUSCO_WL_OUT_LN_W), LW(l, DIFUSCO_WL_OUT_LN_B),
+                                               ws.tbias + (size_t)l * H, tsp ? 1 : 0, st))
+    PROF(PROF_LINEAR_EDGE, linear_rows(ws.tmp, LW(l, DIFUSCO_WL_OUT_W), LW(l, DIFUSCO_WL_OUT_B), ws.e, ws.e, E, H, H, H, st))
+  }
+
+  // head + posterior (gnn_encoder.py:400-401 / :412-413, pl_tsp_model.py:133-137, pl_meta_model.py:102-175)
+  PROF(PROF_HEAD, launch_head(H, C, tsp ? ws.e : ws.h, a->n_segments > 1 ? a->seg_ptr : nullptr, a->n_segments, out_rows,
+                              gn_blocks_for(out_rows), ws.partial, ws.stats, G(DIFUSCO_W_OUT_GN_W), G(DIFUSCO_W_OUT_GN_B),
+                              G(DIFUSCO_W_OUT_CONV_W), G(DIFUSCO_W_OUT_CONV_B), tsp ? a->perm : nullptr, a->xt, a->post,
+                              a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st))
+#undef PROF
+  return DIFUSCO_OK;
+}
+
+int difusco_linear_rows(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t m,
+                        int k, int n_out, int64_t ldy, void* stream) {
+  if (!x || !w || !y) return fail(DIFUSCO_EINVAL, "null pointer");
+  if (!(k == 32 || k == 64 || k == 128 || k == 256) || n_out % 32 != 0 || n_out <= 0 || ldy < n_out)
+    return fail(DIFUSCO_EINVAL, "k must be 32/64/128/256, n_out a positive multiple of 32, ldy >= n_out");
+  HIP_TRY(difusco::linear_rows(x, w, bias, residual, y, m, k, n_out, ldy, (hipStream_t)stream));
+  return DIFUSCO_OK;
+}
+
+int difusco_edge_gate_aggregate(int hidden, int n_nodes, const int32_t* rowptr, const int32_t* col, const float* node4,
+                                float* ce_act, float* h, const float* norm_h_w, const float* norm_h_b,
+                                const float* norm_e_w, const float* norm_e_b, const float* out_ln_w,
+                                const float* out_ln_b, const float* tbias, int time_on_edge, void* stream) {
+  if (!hidden_ok(hidden)) return fail(DIFUSCO_EINVAL, "hidden must be 64, 128 or 256");
+  if (!rowptr || !node4 || !h || !norm_h_w || !norm_h_b || !norm_e_w || !norm_e_b || !out_ln_w || !out_ln_b || !tbias)
+    return fail(DIFUSCO_EINVAL, "null pointer");
+  HIP_TRY(difusco::launch_edge_gate_aggregate(hidden, n_nodes, rowptr, col, node4, ce_act, h, norm_h_w, norm_h_b, norm_e_w,
+                                              norm_e_b, out_ln_w, out_ln_b, tbias, time_on_edge, (hipStream_t)stream));
+  return DIFUSCO_OK;
+}
+
+int difusco_categorical_posterior(const float* logits, const float* xt, const float* post, int rand_mode,
+                                  const float* rand, uint64_t seed, uint64_t offset, float* xt_out, float* prob_out,
+                                  int64_t n, void* stream) {
+  if (!logits || !xt || !post || !xt_out) return fail(DIFUSCO_EINVAL, "null pointer");
+  if (post[4] != 0.0f && (rand_mode == DIFUSCO_RAND_NONE || (rand_mode == DIFUSCO_RAND_INJECTED && !rand)))
+    return fail(DIFUSCO_EINVAL, "this step draws random numbers: provide rand or use PHILOX");
+  HIP_TRY(difusco::launch_categorical_posterior(logits, xt, post, rand_mode, rand, seed, offset, xt_out, prob_out, n,
+                                                (hipStream_t)stream));
+  return DIFUSCO_OK;
+}
+
+int difusco_gaussian_posterior(const float* pred, const float* xt, const float* post, int rand_mode, const float* rand,
+                               uint64_t seed, uint64_t offset, float* xt_out, int64_t n, void* stream) {
+  if (!pred || !xt || !post || !xt_out) return fail(DIFUSCO_EINVAL, "null pointer");
+  if (post[4] != 0.0f && (rand_mode == DIFUSCO_RAND_NONE || (rand_mode == DIFUSCO_RAND_INJECTED && !rand)))
+    return fail(DIFUSCO_EINVAL, "this step draws random numbers: provide rand or use PHILOX");
+  HIP_TRY(difusco::launch_gaussian_posterior(pred, xt, post, rand_mode, rand, seed, offset, xt_out, n, (hipStream_t)stream));
+  return DIFUSCO_OK;
+}
+
+int difusco_profile_enable(int on, int max_launches) {
+  if (on) {
+    if (max_launches < 1) max_launches = 1;
+    while (g_prof.ev.size() < (size_t)max_launches * 2) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      g_prof.ev.push_back(e);
+    }
+    g_prof.cat.assign(g_prof.ev.size() / 2, 0);
+    g_prof.used = 0;
+  }
+  g_prof.on = on != 0;
+  return DIFUSCO_OK;
+}
+
+int difusco_profile_collect(double* ms, int64_t* launches, int n_categories) {
+  if (!ms || !launches || n_categories < PROF_NCAT) return fail(DIFUSCO_EINVAL, "need %d categories", PROF_NCAT);
+  for (int c = 0; c < n_categories; ++c) { ms[c] = 0.0; launches[c] = 0; }
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    HIP_TRY(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+    float t = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    ms[g_prof.cat[i]] += t;
+    launches[g_prof.cat[i]] += 1;
+  }
+  const int used = (int)g_prof.used;
+  g_prof.used = 0;
+  return used;
+}
+
+}  // extern "C"

@@ -1,0 +1,531 @@
+// HBM-bound kernels of the DIFUSCO denoise step for gfx950: embeddings, the CSR edge-gate /
+// neighbour-aggregation pass, the GroupNorm head and the reverse-diffusion posteriors.
+//
+// Feature layout everywhere: a [rows, H] fp32 row is spread over the 64 lanes of ONE wavefront,
+// lane l owning the VEC = H/64 consecutive channels [l*VEC, (l+1)*VEC) (H=256 -> one float4 per lane,
+// 1 KiB per row per wave instruction, fully coalesced).  Reductions over H (LayerNorm, the 1x1 conv)
+// are wavefront butterflies; the neighbour sum over a node's edges is a per-lane register
+// accumulation by the wave that owns the node (deterministic order, no atomics).
+#include "common.h"
+#include "kernels.h"
+
+namespace difusco {
+
+template <int VEC>
+struct Vec {
+  float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> ldv(const float* p) {
+  Vec<VEC> r;
+  if constexpr (VEC == 4) {
+    const v4f t = *reinterpret_cast<const v4f*>(p);
+    r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3];
+  } else if constexpr (VEC == 2) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f t = *reinterpret_cast<const v2f*>(p);
+    r.v[0] = t[0]; r.v[1] = t[1];
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const Vec<VEC>& r) {
+  if constexpr (VEC == 4) {
+    v4f t;
+    t[0] = r.v[0]; t[1] = r.v[1]; t[2] = r.v[2]; t[3] = r.v[3];
+    *reinterpret_cast<v4f*>(p) = t;
+  } else if constexpr (VEC == 2) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f t;
+    t[0] = r.v[0]; t[1] = r.v[1];
+    *reinterpret_cast<v2f*>(p) = t;
+  } else {
+    *p = r.v[0];
+  }
+}
+
+// LayerNorm over the H = 64*VEC channels held by one wavefront (eps 1e-5, biased variance,
+// torch.nn.LayerNorm semantics; gnn_encoder.py:58-65).  Two-pass on registers.
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> wave_layer_norm(const Vec<VEC>& x, const Vec<VEC>& gamma, const Vec<VEC>& beta) {
+  constexpr float inv_h = 1.0f / (64 * VEC);
+  float s = 0.0f;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s += x.v[v];
+  const float mean = wave_sum(s) * inv_h;
+  float q = 0.0f;
+  Vec<VEC> d;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    d.v[v] = x.v[v] - mean;
+    q += d.v[v] * d.v[v];
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_h + 1e-5f);
+  Vec<VEC> y;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) y.v[v] = d.v[v] * rstd * gamma.v[v] + beta.v[v];
+  return y;
+}
+
+// ------------------------------------------------------------------------------------------------
+// time features: timestep_embedding -> time_embed MLP -> per-layer ReLU+Linear
+// (models/nn.py:103-121, gnn_encoder.py:311-315, :329-337).  One workgroup per layer; one [1,H]
+// row per layer per step, so this is latency-, not bandwidth-relevant.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_bias_kernel(float t, int H, const float* __restrict__ freqs,
+                                                        const float* __restrict__ w0, const float* __restrict__ b0,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        const float* __restrict__ wl_base, long long layer_stride,
+                                                        long long wl_w_off, long long wl_b_off, float* __restrict__ tbias) {
+  __shared__ float emb[256];
+  __shared__ float h1[128];
+  __shared__ float te[128];
+  const int half = H / 2;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < half; k += 256) {
+    const float a = t * freqs[k];
+    emb[k] = cosf(a);
+    emb[half + k] = sinf(a);
+  }
+  __syncthreads();
+  for (int o = tid; o < half; o += 256) {
+    float s = 0.0f;
+    for (int k = 0; k < H; ++k) s += w0[o * H + k] * emb[k];
+    s += b0[o];
+    h1[o] = s > 0.0f ? s : 0.0f;
+  }
+  __syncthreads();
+  for (int o = tid; o < half; o += 256) {
+    float s = 0.0f;
+    for (int k = 0; k < half; ++k) s += w2[o * half + k] * h1[k];
+    s += b2[o];
+    te[o] = s > 0.0f ? s : 0.0f;  // the ReLU that opens every time_embed_layers[l]
+  }
+  __syncthreads();
+  const int l = blockIdx.x;
+  const float* wl = wl_base + l * layer_stride + wl_w_off;
+  const float* bl = wl_base + l * layer_stride + wl_b_off;
+  for (int o = tid; o < H; o += 256) {
+    float s = 0.0f;
+    for (int k = 0; k < half; ++k) s += wl[o * half + k] * te[k];
+    tbias[l * H + o] = s + bl[o];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sinusoidal input embeddings (inputs of node_embed / edge_embed)
+// ------------------------------------------------------------------------------------------------
+// PositionEmbeddingSine(H/2, normalize=True): gnn_encoder.py:194-227.  out[n, 0:H/2] from coord 0,
+// out[n, H/2:H] from coord 1; even channel sin, odd channel cos.
+__global__ void pos_embed_kernel(const float* __restrict__ points, const float* __restrict__ dimt, int n_nodes, int H,
+                                 float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)n_nodes * H) return;
+  const int c = (int)(idx % H);
+  const long long n = idx / H;
+  const int half = H / 2;
+  const int coord = c < half ? 0 : 1;
+  const int k = c < half ? c : c - half;
+  const float v = (points[n * 2 + coord] * 6.283185307179586f) / dimt[k];
+  out[idx] = (k & 1) ? cosf(v) : sinf(v);
+}
+
+// ScalarEmbeddingSine / ScalarEmbeddingSine1D: gnn_encoder.py:230-271.  x index through `perm`
+// (CSR slot -> caller order) when given.
+__global__ void scalar_embed_kernel(const float* __restrict__ x, const int* __restrict__ perm,
+                                    const float* __restrict__ dimt, long long rows, int H, float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * H) return;
+  const int c = (int)(idx % H);
+  const long long r = idx / H;
+  const float xv = x ? x[perm ? perm[r] : r] : (float)r;  // x == nullptr: rows are the constants 0,1,...
+  const float v = xv / dimt[c];
+  out[idx] = (c & 1) ? cosf(v) : sinf(v);
+}
+
+// categorical inference: xt is exactly 0/1, so edge_embed(ScalarEmbeddingSine(xt)) has two distinct
+// rows; table = those two rows (computed by the same embed+linear kernels on x = {0,1}).
+template <int VEC>
+__global__ __launch_bounds__(256) void table_rows_kernel(const float* __restrict__ x, const int* __restrict__ perm,
+                                                         const float* __restrict__ table, long long rows,
+                                                         float* __restrict__ out) {
+  constexpr int H = 64 * VEC;
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const Vec<VEC> r0 = ldv<VEC>(table + lane * VEC);
+  const Vec<VEC> r1 = ldv<VEC>(table + H + lane * VEC);
+  for (long long r = wave0; r < rows; r += nwaves) {
+    const float xv = x[perm ? perm[r] : r];
+    stv<VEC>(out + r * H + lane * VEC, xv > 0.5f ? r1 : r0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR edge gate + neighbour aggregation + the two LayerNorms on the edge row
+//   e'    = Ah[j] + Bh[i] + Ce                         gnn_encoder.py:110
+//   agg_i = sum_j sigmoid(e') * Vh[j]                  :112,:115,:163,:177-191 (aggregation='sum')
+//   h_i  += ReLU(LN_h(Uh[i] + agg_i)) (+ tbias, MIS)   :123,:134,:447-448
+//   act   = SiLU(LN_o(ReLU(LN_e(e')) (+ tbias, TSP)))  :131,:135,:445, per_layer_out[l][0:2] :339-342
+// One wavefront owns one centre node i and walks its CSR row (latency of the four dependent wave
+// reductions per edge is hidden by the other resident waves: the kernel needs few registers).
+// node4 = [n_nodes, 4H] with rows U|V|A|B.  ce_act: in = C e + bias, out = act (same slot, same lane).
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void edge_gate_aggregate_kernel(
+    int n_nodes, const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ node4,
+    float* ce_act, float* h, const float* __restrict__ nh_w, const float* __restrict__ nh_b,
+    const float* __restrict__ ne_w, const float* __restrict__ ne_b, const float* __restrict__ ol_w,
+    const float* __restrict__ ol_b, const float* __restrict__ tbias, int time_on_edge) {
+  constexpr int H = 64 * VEC;
+  const int lane = threadIdx.x & 63;
+  const int f = lane * VEC;
+  // wave-uniform node id, made provably uniform so row pointers / neighbour ids are scalar loads
+  const int i = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (i >= n_nodes) return;
+
+  const float* ni = node4 + (long long)i * 4 * H;
+  const Vec<VEC> uh = ldv<VEC>(ni + f);
+  const Vec<VEC> bh = ldv<VEC>(ni + 3 * H + f);
+  const Vec<VEC> g_e = ldv<VEC>(ne_w + f), b_e = ldv<VEC>(ne_b + f);
+  const Vec<VEC> g_o = ldv<VEC>(ol_w + f), b_o = ldv<VEC>(ol_b + f);
+  const Vec<VEC> tb = ldv<VEC>(tbias + f);
+
+  Vec<VEC> agg;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) agg.v[v] = 0.0f;
+
+  const int s_begin = rowptr[i], s_end = rowptr[i + 1];
+  for (int s = s_begin; s < s_end; ++s) {
+    const int j = col[s];
+    const float* nj = node4 + (long long)j * 4 * H;
+    const Vec<VEC> vh = ldv<VEC>(nj + H + f);
+    const Vec<VEC> ah = ldv<VEC>(nj + 2 * H + f);
+    float* cp = ce_act + (long long)s * H + f;
+    const Vec<VEC> ce = ldv<VEC>(cp);
+    Vec<VEC> e;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      e.v[v] = (ah.v[v] + bh.v[v]) + ce.v[v];
+      agg.v[v] += sigmoidf_(e.v[v]) * vh.v[v];
+    }
+    Vec<VEC> y = wave_layer_norm<VEC>(e, g_e, b_e);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      y.v[v] = y.v[v] > 0.0f ? y.v[v] : 0.0f;
+      if (time_on_edge) y.v[v] += tb.v[v];
+    }
+    Vec<VEC> z = wave_layer_norm<VEC>(y, g_o, b_o);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) z.v[v] = z.v[v] * sigmoidf_(z.v[v]);
+    stv<VEC>(cp, z);
+  }
+
+  Vec<VEC> hn;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) hn.v[v] = uh.v[v] + agg.v[v];
+  const Vec<VEC> g_h = ldv<VEC>(nh_w + f), b_h = ldv<VEC>(nh_b + f);
+  hn = wave_layer_norm<VEC>(hn, g_h, b_h);
+  float* hp = h + (long long)i * H + f;
+  Vec<VEC> hi = ldv<VEC>(hp);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    float r = hn.v[v] > 0.0f ? hn.v[v] : 0.0f;
+    if (!time_on_edge) r += tb.v[v];
+    hi.v[v] += r;
+  }
+  stv<VEC>(hp, hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: GroupNorm32(32,H) statistics over (H/32 channels x all rows of a segment)
+// (gnn_encoder.py:316-322,400-401,412-413; nn.py:17-19,93-100).  A group = 2 adjacent lanes.
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ feat, const int* __restrict__ seg_ptr,
+                                                         long long total_rows, double* __restrict__ partial) {
+  constexpr int H = 64 * VEC;
+  __shared__ double red[4][32][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = blockIdx.y;
+  const long long r_begin = seg_ptr ? seg_ptr[seg] : 0;
+  const long long r_end = seg_ptr ? seg_ptr[seg + 1] : total_rows;
+  double s = 0.0, q = 0.0;
+  for (long long r = r_begin + blockIdx.x * 4 + wave; r < r_end; r += (long long)gridDim.x * 4) {
+    const Vec<VEC> x = ldv<VEC>(feat + r * H + lane * VEC);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      s += (double)x.v[v];
+      q += (double)x.v[v] * (double)x.v[v];
+    }
+  }
+  s += __shfl_xor(s, 1, 64);
+  q += __shfl_xor(q, 1, 64);
+  if ((lane & 1) == 0) {
+    red[wave][lane >> 1][0] = s;
+    red[wave][lane >> 1][1] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int g = threadIdx.x >> 1, w = threadIdx.x & 1;
+    const double t = red[0][g][w] + red[1][g][w] + red[2][g][w] + red[3][g][w];
+    partial[((long long)seg * gridDim.x + blockIdx.x) * 64 + g * 2 + w] = t;
+  }
+}
+
+// stats[seg][g] = {mean, rstd}; one 64-thread block per segment, fixed summation order.
+__global__ void gn_finalize_kernel(const double* __restrict__ partial, const int* __restrict__ seg_ptr,
+                                   long long total_rows, int nblk, int ch_per_group, float* __restrict__ stats) {
+  const int seg = blockIdx.x;
+  const int g = threadIdx.x;
+  if (g >= 32) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += partial[((long long)seg * nblk + b) * 64 + g * 2 + 0];
+    q += partial[((long long)seg * nblk + b) * 64 + g * 2 + 1];
+  }
+  const long long rows = seg_ptr ? (long long)(seg_ptr[seg + 1] - seg_ptr[seg]) : total_rows;
+  const double cnt = (double)rows * ch_per_group;
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  stats[(seg * 32 + g) * 2 + 0] = (float)mean;
+  stats[(seg * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+// ---- posterior arithmetic (shared by the fused head and the stand-alone kernels) -------------------
+// categorical: pl_tsp_model.py:133-135 (softmax over the 2 classes) + pl_meta_model.py:125-142.
+// post = {c0[xt=0], c0[xt=1], c1[xt=0], c1[xt=1], draw}.
+struct PostParams {
+  float p[8];
+  int rand_mode;
+  const float* rand;
+  unsigned long long seed, offset;
+};
+
+__device__ __forceinline__ float categorical_step(float l0, float l1, float xt, const PostParams& pp, long long idx,
+                                                  float* prob_out) {
+  const float m = fmaxf(l0, l1);
+  const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+  const float den = e0 + e1;
+  const float p0 = e0 / den, p1 = e1 / den;
+  const int b = xt > 0.5f ? 1 : 0;
+  const float prob = __fadd_rn(__fmul_rn(pp.p[b], p0), __fmul_rn(pp.p[2 + b], p1));
+  if (prob_out) *prob_out = prob;
+  if (pp.p[4] != 0.0f) {
+    const float pc = fminf(fmaxf(prob, 0.0f), 1.0f);
+    float u;
+    if (pp.rand_mode == 1) u = pp.rand[idx];
+    else u = philox_uniform(pp.seed, pp.offset, (unsigned long long)idx);
+    return u < pc ? 1.0f : 0.0f;
+  }
+  return fmaxf(prob, 0.0f);
+}
+
+// gaussian: pl_meta_model.py:161-172.  post = {a, b, c, d, branch}: branch 0 (DDIM)
+//   x = a*(xt - b*pred) + c*pred ; branch 1 (DDPM) x = a*(xt - b*pred) + d*z.
+__device__ __forceinline__ float gaussian_step(float pred, float xt, const PostParams& pp, long long idx) {
+  const float base = __fmul_rn(pp.p[0], __fsub_rn(xt, __fmul_rn(pp.p[1], pred)));
+  if (pp.p[4] == 0.0f) return __fadd_rn(base, __fmul_rn(pp.p[2], pred));
+  float z;
+  if (pp.rand_mode == 1) z = pp.rand[idx];
+  else z = philox_normal(pp.seed, pp.offset, (unsigned long long)idx);
+  return __fadd_rn(base, __fmul_rn(pp.p[3], z));
+}
+
+// head apply: GroupNorm affine -> ReLU -> 1x1 conv (C = 1 or 2) -> softmax/posterior/sample.
+// One wavefront per output row.  Outputs are written in CALLER order (through perm).
+template <int VEC, int C>
+__global__ __launch_bounds__(256) void head_apply_kernel(const float* __restrict__ feat, const int* __restrict__ seg_ptr,
+                                                         long long total_rows, const float* __restrict__ stats,
+                                                         const float* __restrict__ gn_w, const float* __restrict__ gn_b,
+                                                         const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+                                                         const int* __restrict__ perm, const float* __restrict__ xt,
+                                                         PostParams pp, float* __restrict__ xt_out,
+                                                         float* __restrict__ pred_out, float* __restrict__ prob_out) {
+  constexpr int H = 64 * VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = blockIdx.y;
+  const long long r_begin = seg_ptr ? seg_ptr[seg] : 0;
+  const long long r_end = seg_ptr ? seg_ptr[seg + 1] : total_rows;
+  const float mean = stats[(seg * 32 + (lane >> 1)) * 2 + 0];
+  const float rstd = stats[(seg * 32 + (lane >> 1)) * 2 + 1];
+  const Vec<VEC> gw = ldv<VEC>(gn_w + lane * VEC), gb = ldv<VEC>(gn_b + lane * VEC);
+  Vec<VEC> cw[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) cw[c] = ldv<VEC>(conv_w + c * H + lane * VEC);
+  for (long long r = r_begin + blockIdx.x * 4 + wave; r < r_end; r += (long long)gridDim.x * 4) {
+    const Vec<VEC> x = ldv<VEC>(feat + r * H + lane * VEC);
+    float dot[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dot[c] = 0.0f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float y = (x.v[v] - mean) * rstd * gw.v[v] + gb.v[v];
+      y = y > 0.0f ? y : 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) dot[c] += y * cw[c].v[v];
+    }
+    if constexpr (C == 2) {
+      wave_sum2(dot[0], dot[1]);
+    } else {
+      dot[0] = wave_sum(dot[0]);
+    }
+    if (lane == 0) {
+      const long long idx = perm ? perm[r] : r;
+      if constexpr (C == 2) {
+        const float l0 = dot[0] + conv_b[0], l1 = dot[1] + conv_b[1];
+        if (pred_out) {
+          pred_out[idx * 2 + 0] = l0;
+          pred_out[idx * 2 + 1] = l1;
+        }
+        xt_out[idx] = categorical_step(l0, l1, xt[idx], pp, idx, prob_out ? prob_out + idx : nullptr);
+      } else {
+        const float pred = dot[0] + conv_b[0];
+        if (pred_out) pred_out[idx] = pred;
+        xt_out[idx] = gaussian_step(pred, xt[idx], pp, idx);
+      }
+    }
+  }
+}
+
+__global__ void categorical_posterior_kernel(const float* __restrict__ logits, const float* __restrict__ xt,
+                                             PostParams pp, float* __restrict__ xt_out, float* __restrict__ prob_out,
+                                             long long n) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  xt_out[idx] = categorical_step(logits[idx * 2], logits[idx * 2 + 1], xt[idx], pp, idx,
+                                 prob_out ? prob_out + idx : nullptr);
+}
+
+__global__ void gaussian_posterior_kernel(const float* __restrict__ pred, const float* __restrict__ xt, PostParams pp,
+                                          float* __restrict__ xt_out, long long n) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  xt_out[idx] = gaussian_step(pred[idx], xt[idx], pp, idx);
+}
+
+// ================================================================================================
+// host-side launchers
+// ================================================================================================
+#define DIFUSCO_VEC_DISPATCH(H, CALL)      \
+  switch (H) {                             \
+    case 64: { constexpr int VEC = 1; CALL; } break;  \
+    case 128: { constexpr int VEC = 2; CALL; } break; \
+    case 256: { constexpr int VEC = 4; CALL; } break; \
+    default: return hipErrorInvalidValue;  \
+  }
+
+hipError_t launch_time_bias(float t, int H, int n_layers, const float* freqs, const float* w0, const float* b0,
+                            const float* w2, const float* b2, const float* wl_base, long long layer_stride,
+                            long long wl_w_off, long long wl_b_off, float* tbias, hipStream_t stream) {
+  if (H > 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(time_bias_kernel, dim3(n_layers), dim3(256), 0, stream, t, H, freqs, w0, b0, w2, b2, wl_base,
+                     layer_stride, wl_w_off, wl_b_off, tbias);
+  return hipGetLastError();
+}
+
+hipError_t launch_pos_embed(const float* points, const float* dimt, int n_nodes, int H, float* out, hipStream_t stream) {
+  const long long n = (long long)n_nodes * H;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(pos_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, points, dimt, n_nodes, H, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_scalar_embed(const float* x, const int* perm, const float* dimt, long long rows, int H, float* out,
+                               hipStream_t stream) {
+  const long long n = rows * H;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(scalar_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, perm, dimt, rows, H, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_table_rows(const float* x, const int* perm, const float* table, long long rows, int H, float* out,
+                             hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  long long blocks = (rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((table_rows_kernel<VEC>), dim3((unsigned)blocks), dim3(256), 0, stream, x,
+                                             perm, table, rows, out))
+  return hipGetLastError();
+}
+
+hipError_t launch_edge_gate_aggregate(int H, int n_nodes, const int* rowptr, const int* col, const float* node4,
+                                      float* ce_act, float* h, const float* nh_w, const float* nh_b, const float* ne_w,
+                                      const float* ne_b, const float* ol_w, const float* ol_b, const float* tbias,
+                                      int time_on_edge, hipStream_t stream) {
+  if (n_nodes == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n_nodes + 3) / 4);
+  DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((edge_gate_aggregate_kernel<VEC>), dim3(blocks), dim3(256), 0, stream,
+                                             n_nodes, rowptr, col, node4, ce_act, h, nh_w, nh_b, ne_w, ne_b, ol_w, ol_b,
+                                             tbias, time_on_edge))
+  return hipGetLastError();
+}
+
+int gn_blocks_for(long long rows) {
+  long long b = (rows + 63) / 64;  // >= 16 rows per wave
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+
+hipError_t launch_head(int H, int C, const float* feat, const int* seg_ptr, int n_segments, long long total_rows,
+                       int nblk, double* partial, float* stats, const float* gn_w, const float* gn_b,
+                       const float* conv_w, const float* conv_b, const int* perm, const float* xt, const float* post,
+                       int rand_mode, const float* rand, unsigned long long seed, unsigned long long offset,
+                       float* xt_out, float* pred_out, float* prob_out, hipStream_t stream) {
+  if (total_rows == 0) return hipSuccess;
+  PostParams pp;
+  for (int i = 0; i < 8; ++i) pp.p[i] = post[i];
+  pp.rand_mode = rand_mode;
+  pp.rand = rand;
+  pp.seed = seed;
+  pp.offset = offset;
+  dim3 grid((unsigned)nblk, (unsigned)n_segments);
+  DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((gn_partial_kernel<VEC>), grid, dim3(256), 0, stream, feat, seg_ptr,
+                                             total_rows, partial))
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segments), dim3(64), 0, stream, partial, seg_ptr, total_rows, nblk, H / 32,
+                     stats);
+  if (C == 2) {
+    DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((head_apply_kernel<VEC, 2>), grid, dim3(256), 0, stream, feat, seg_ptr,
+                                               total_rows, stats, gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out,
+                                               pred_out, prob_out))
+  } else if (C == 1) {
+    DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((head_apply_kernel<VEC, 1>), grid, dim3(256), 0, stream, feat, seg_ptr,
+                                               total_rows, stats, gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out,
+                                               pred_out, prob_out))
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_categorical_posterior(const float* logits, const float* xt, const float* post, int rand_mode,
+                                        const float* rand, unsigned long long seed, unsigned long long offset,
+                                        float* xt_out, float* prob_out, long long n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  PostParams pp;
+  for (int i = 0; i < 8; ++i) pp.p[i] = post[i];
+  pp.rand_mode = rand_mode; pp.rand = rand; pp.seed = seed; pp.offset = offset;
+  hipLaunchKernelGGL(categorical_posterior_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, logits, xt, pp,
+                     xt_out, prob_out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_gaussian_posterior(const float* pred, const float* xt, const float* post, int rand_mode,
+                                     const float* rand, unsigned long long seed, unsigned long long offset, float* xt_out,
+                                     long long n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  PostParams pp;
+  for (int i = 0; i < 8; ++i) pp.p[i] = post[i];
+  pp.rand_mode = rand_mode; pp.rand = rand; pp.seed = seed; pp.offset = offset;
+  hipLaunchKernelGGL(gaussian_posterior_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pred, xt, pp,
+                     xt_out, n);
+  return hipGetLastError();
+}
+
+}  // namespace difusco

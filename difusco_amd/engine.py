@@ -1,0 +1,93 @@
+"""The denoise-step engine: owns the packed weights and the workspace on one GPU and drives
+``difusco_denoise_step`` (C ABI).  PyTorch is used for device memory and streams only."""
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph import CsrGraph
+from .weights import infer_config, pack_state_dict
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class DenoiseEngine:
+    def __init__(self, state_dict, device="cuda:0", blob: Optional[torch.Tensor] = None):
+        """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
+        ``blob``: an already packed blob (e.g. received by RCCL broadcast) instead of packing here."""
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.DifuscoHipError("DenoiseEngine needs a GPU device (no CPU fallback exists)")
+        _lib.lib()  # fail loudly, now, if the HIP library is missing
+        self.hidden, self.n_layers, self.out_channels = infer_config(state_dict)
+        if blob is None:
+            blob = pack_state_dict(state_dict)
+        self.blob = blob.to(self.device, dtype=torch.float32).contiguous()
+        self._ws = None
+        self.calls = 0
+
+    # ---- workspace -----------------------------------------------------------------------------
+    def _workspace(self, g: CsrGraph) -> torch.Tensor:
+        need = _lib.lib().difusco_workspace_bytes(self.hidden, self.n_layers, g.n_nodes, g.n_edges, g.n_segments)
+        if need == 0:
+            raise _lib.DifuscoHipError("difusco_workspace_bytes rejected the problem shape")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---- one step ------------------------------------------------------------------------------
+    def step(self, g: CsrGraph, task: int, diffusion: int, xt: torch.Tensor, t: float, post: np.ndarray,
+             points: Optional[torch.Tensor] = None, xt_is_binary: bool = False,
+             rand: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
+             want_pred: bool = False, want_prob: bool = False):
+        """xt: fp32, TSP [E] in caller edge order / MIS [N].  Returns (xt_next, pred|None, prob|None);
+        asynchronous on the current stream."""
+        dev = self.device
+        xt = xt.to(dev, dtype=torch.float32).contiguous().reshape(-1)
+        rows = g.n_edges if task == _lib.TASK_TSP else g.n_nodes
+        if xt.numel() != rows:
+            raise ValueError(f"xt has {xt.numel()} elements, the graph has {rows} output rows")
+        if points is not None:
+            points = points.to(dev, dtype=torch.float32).contiguous()
+            if points.numel() != 2 * g.n_nodes:
+                raise ValueError("points must be [n_nodes, 2]")
+        draws = float(post[4]) != 0.0
+        if rand is not None:
+            rand = rand.to(dev, dtype=torch.float32).contiguous().reshape(-1)
+            if rand.numel() != rows:
+                raise ValueError("injected randomness must have one value per output row")
+        xt_out = torch.empty(rows, dtype=torch.float32, device=dev)
+        C = self.out_channels
+        pred = torch.empty((rows, 2) if C == 2 else (rows,), dtype=torch.float32, device=dev) if want_pred else None
+        prob = torch.empty(rows, dtype=torch.float32, device=dev) if (want_prob and C == 2) else None
+        ws = self._workspace(g)
+
+        a = _lib.StepArgs()
+        a.struct_size = ctypes.sizeof(_lib.StepArgs)
+        a.abi_version = _lib.ABI_VERSION
+        a.hidden, a.n_layers, a.out_channels, a.task = self.hidden, self.n_layers, C, task
+        a.weights = _ptr(self.blob)
+        a.n_nodes, a.n_edges = g.n_nodes, g.n_edges
+        a.rowptr, a.col, a.perm = _ptr(g.rowptr), _ptr(g.col), _ptr(g.perm)
+        a.n_segments, a.seg_ptr = g.n_segments, _ptr(g.seg_ptr)
+        a.points, a.xt = _ptr(points), _ptr(xt)
+        a.t = float(t)
+        a.xt_is_binary = 1 if xt_is_binary else 0
+        a.diffusion = diffusion
+        for i in range(8):
+            a.post[i] = float(post[i]) if i < len(post) else 0.0
+        a.rand_mode = _lib.RAND_INJECTED if rand is not None else (_lib.RAND_PHILOX if draws else _lib.RAND_NONE)
+        a.rand = _ptr(rand)
+        a.seed, a.offset = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1)
+        a.xt_out, a.pred_out, a.prob_out = _ptr(xt_out), _ptr(pred), _ptr(prob)
+        a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
+        a.stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
+        self.calls += 1
+        return xt_out, pred, prob

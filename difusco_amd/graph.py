@@ -1,0 +1,72 @@
+"""Graph layout: COO ``edge_index`` (reference contract) -> CSR over the centre node, int32, on device.
+
+Input contract: ``edge_index[0]`` = centre node i, ``edge_index[1]`` = neighbour
+j; TSP k-NN graphs are row-sorted with constant degree and include the self edge
+(``co_datasets/tsp_graph_dataset.py:53-62``); MIS graphs are undirected edges + reversed copy + self
+loops, not row-sorted (``co_datasets/mis_dataset.py:43-48``); a batch is the disjoint union with node
+ids offset per graph (``pl_meta_model.py:177-184``).  The conversion runs once per instance, outside
+the denoising loop, on the host (C helper ``difusco_csr_from_coo_host``).
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class CsrGraph:
+    n_nodes: int
+    n_edges: int
+    rowptr: torch.Tensor            # int32 [n_nodes+1], device
+    col: torch.Tensor               # int32 [n_edges], device
+    perm: Optional[torch.Tensor]    # int32 [n_edges] CSR slot -> caller edge id; None = identity
+    seg_ptr: Optional[torch.Tensor] = None   # int32 [S+1] device; GroupNorm statistic segments
+    n_segments: int = 1
+
+
+def csr_from_coo_host(edge_index: np.ndarray, n_nodes: int):
+    """numpy int64 [2,E] -> (rowptr, col, row, perm, identity) int32 numpy arrays."""
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    assert ei.ndim == 2 and ei.shape[0] == 2
+    E = ei.shape[1]
+    rowptr = np.empty(n_nodes + 1, dtype=np.int32)
+    col = np.empty(E, dtype=np.int32)
+    row = np.empty(E, dtype=np.int32)
+    perm = np.empty(E, dtype=np.int32)
+    ident = ctypes.c_int(0)
+    _lib.check(_lib.lib().difusco_csr_from_coo_host(
+        ei.ctypes.data, E, n_nodes, rowptr.ctypes.data, col.ctypes.data, row.ctypes.data, perm.ctypes.data,
+        ctypes.byref(ident)))
+    return rowptr, col, row, perm, bool(ident.value)
+
+
+def build_csr(edge_index: torch.Tensor, n_nodes: int, device, seg_rows: Optional[np.ndarray] = None) -> CsrGraph:
+    """edge_index int64 [2,E] (any device).  ``seg_rows``: boundaries [S+1] of the head-GroupNorm
+    statistic segments over output rows (None = one segment = the reference's sparse behaviour)."""
+    rowptr, col, _row, perm, ident = csr_from_coo_host(edge_index.detach().cpu().numpy(), n_nodes)
+    g = CsrGraph(
+        n_nodes=n_nodes, n_edges=int(col.shape[0]),
+        rowptr=torch.from_numpy(rowptr).to(device), col=torch.from_numpy(col).to(device),
+        perm=None if ident else torch.from_numpy(perm).to(device))
+    if seg_rows is not None and len(seg_rows) > 2:
+        g.seg_ptr = torch.from_numpy(np.asarray(seg_rows, dtype=np.int32)).to(device)
+        g.n_segments = len(seg_rows) - 1
+    return g
+
+
+def complete_graph_batch(batch: int, n: int, device) -> CsrGraph:
+    """Dense mode (``gnn_encoder.py:350-381``): B graphs with all n*n ordered pairs, edge (b,i,j) at slot
+    b*n*n + i*n + j - exactly the flattening of the reference's [B,V,V] tensors.  One GroupNorm
+    statistic segment per sample (the dense head normalises a (B,H,V,V) tensor)."""
+    rowptr = (torch.arange(batch * n + 1, dtype=torch.int64) * n).to(torch.int32)
+    col = (torch.arange(n, dtype=torch.int32).repeat(batch * n)
+           + torch.arange(batch, dtype=torch.int32).repeat_interleave(n * n) * n)
+    g = CsrGraph(n_nodes=batch * n, n_edges=batch * n * n, rowptr=rowptr.to(device), col=col.to(device), perm=None)
+    if batch > 1:
+        g.seg_ptr = (torch.arange(batch + 1, dtype=torch.int64) * n * n).to(torch.int32).to(device)
+        g.n_segments = batch
+    return g

@@ -1,0 +1,227 @@
+"""Drop-in host side of the denoise step: ``TSPModel`` / ``MISModel`` with the reference's method
+names, argument order and argument meaning (``difusco/pl_tsp_model.py:122-151``,
+``difusco/pl_mis_model.py:118-140``), backed by the gfx950 library instead of the PyTorch-Lightning
+modules.  Only the inference path exists here (no training, data loading, tour decoding).
+
+    model = TSPModel(param_args, state_dict)            # param_args: the reference's argparse namespace
+    xt = model.categorical_denoise_step(points, xt, t, device, edge_index, target_t=target_t)
+
+``t`` / ``target_t`` are numpy int arrays of shape (1,) exactly as the reference's ``test_step`` passes
+them (``pl_tsp_model.py:209-210``); python ints are accepted too.  Returned tensors are new fp32
+tensors on ``device``, flattened in sparse mode (``pl_meta_model.py:144-145``).
+
+Extensions beyond the reference signature are keyword-only: ``uniform=`` / ``noise=`` inject the
+random numbers (teacher-forced parity tests), ``return_aux=True`` also returns the network
+prediction and the pre-sampling probability.
+"""
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import DenoiseEngine
+from .graph import CsrGraph, build_csr, complete_graph_batch
+from .schedules import CategoricalDiffusion, GaussianDiffusion, InferenceSchedule
+
+_DEFAULTS = dict(  # difusco/train.py:19-68 (only what the inference path reads)
+    diffusion_type="gaussian", diffusion_schedule="linear", diffusion_steps=1000,
+    inference_diffusion_steps=1000, inference_schedule="linear", inference_trick="ddim",
+    sequential_sampling=1, parallel_sampling=1, n_layers=12, hidden_dim=256, sparse_factor=-1,
+    aggregation="sum")
+
+
+def _as_int(t) -> int:
+    if t is None:
+        return None
+    return int(np.asarray(t.detach().cpu() if isinstance(t, torch.Tensor) else t).reshape(-1)[0])
+
+
+class COMetaModel:
+    """Inference-side state of the reference's ``COMetaModel`` (``pl_meta_model.py:16-47``): the
+    diffusion tables, the denoiser weights (as a ``DenoiseEngine``) and the two posteriors."""
+
+    def __init__(self, param_args=None, state_dict=None, node_feature_only=False, device="cuda:0",
+                 seed: Optional[int] = None, engine: Optional[DenoiseEngine] = None):
+        args = dict(_DEFAULTS)
+        if param_args is not None:
+            args.update(vars(param_args) if not isinstance(param_args, dict) else param_args)
+        self.args = SimpleNamespace(**args)
+        self.diffusion_type = self.args.diffusion_type
+        self.diffusion_schedule = self.args.diffusion_schedule
+        self.diffusion_steps = self.args.diffusion_steps
+        self.node_feature_only = node_feature_only
+        self.sparse = self.args.sparse_factor > 0 or node_feature_only
+        if self.args.aggregation != "sum":   # gnn_encoder.py:184-188: every published run uses sum
+            raise NotImplementedError("only aggregation='sum' is implemented on the HIP path")
+        if self.diffusion_type == "gaussian":
+            self.diffusion = GaussianDiffusion(T=self.diffusion_steps, schedule=self.diffusion_schedule)
+            out_channels = 1
+        elif self.diffusion_type == "categorical":
+            self.diffusion = CategoricalDiffusion(T=self.diffusion_steps, schedule=self.diffusion_schedule)
+            out_channels = 2
+        else:
+            raise ValueError(f"Unknown diffusion type {self.diffusion_type}")
+        if engine is None:
+            if state_dict is None:
+                raise ValueError("state_dict (reference GNNEncoder weights) or engine required")
+            engine = DenoiseEngine(state_dict, device=device)
+        if engine.out_channels != out_channels:
+            raise ValueError(f"weights have {engine.out_channels} output channels, "
+                             f"{self.diffusion_type} diffusion needs {out_channels}")
+        self.model = engine
+        self.device = engine.device
+        self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
+        self._graph_cache = {}
+
+    # ---- graph handling --------------------------------------------------------------------------
+    def prepare_graph(self, edge_index: torch.Tensor, num_nodes: int) -> CsrGraph:
+        """COO -> CSR once per instance; cached on the identity of ``edge_index`` so the 50 calls of
+        a sampling loop convert once."""
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes))
+        g = self._graph_cache.get(key)
+        if g is None:
+            if len(self._graph_cache) > 8:
+                self._graph_cache.clear()
+            g = build_csr(edge_index, int(num_nodes), self.device)
+            self._graph_cache[key] = (g, edge_index)   # keep edge_index alive: data_ptr stays unique
+            return g
+        return g[0]
+
+    def _dense_graph(self, batch: int, n: int) -> CsrGraph:
+        key = ("dense", batch, n)
+        g = self._graph_cache.get(key)
+        if g is None:
+            g = (complete_graph_batch(batch, n, self.device), None)
+            self._graph_cache[key] = g
+        return g[0]
+
+    def duplicate_edge_index(self, edge_index, num_nodes, device):
+        """Disjoint union of ``parallel_sampling`` replicas (pl_meta_model.py:177-184)."""
+        P = self.args.parallel_sampling
+        shift = torch.arange(0, P, device=device).view(1, -1, 1) * num_nodes
+        return (edge_index.reshape((2, 1, -1)).to(device) + shift).reshape((2, -1))
+
+    # ---- the two step flavours -------------------------------------------------------------------
+    def _next_offset(self) -> int:
+        return self.model.calls
+
+    def _categorical(self, g, task, points, xt, t, target_t, uniform, return_aux):
+        t, target_t = _as_int(t), _as_int(target_t)
+        if target_t is None:
+            target_t = t - 1                                              # pl_meta_model.py:108-109
+        post = np.zeros(8, dtype=np.float32)
+        post[:4] = self.diffusion.posterior_constants(t, target_t)
+        post[4] = 1.0 if target_t > 0 else 0.0                            # :139-142
+        out, pred, prob = self.model.step(
+            g, task, _lib.CATEGORICAL, xt, float(t), post, points=points, xt_is_binary=True,
+            rand=uniform if target_t > 0 else None, seed=self.seed, offset=self._next_offset(),
+            want_pred=return_aux, want_prob=return_aux)
+        return (out, pred, prob) if return_aux else out
+
+    def _gaussian(self, g, task, points, xt, t, target_t, noise, return_aux):
+        t, target_t = _as_int(t), _as_int(target_t)
+        if target_t is None:
+            target_t = t - 1
+        post = np.zeros(8, dtype=np.float32)
+        post[:5] = self.diffusion.posterior_constants(t, target_t, self.args.inference_trick)
+        out, pred, _ = self.model.step(
+            g, task, _lib.GAUSSIAN, xt, float(t), post, points=points, xt_is_binary=False,
+            rand=noise if post[4] != 0 else None, seed=self.seed, offset=self._next_offset(), want_pred=return_aux)
+        return (out, pred) if return_aux else out
+
+
+class TSPModel(COMetaModel):
+    """Inference half of ``difusco/pl_tsp_model.py``."""
+
+    def __init__(self, param_args=None, state_dict=None, **kw):
+        super().__init__(param_args=param_args, state_dict=state_dict, node_feature_only=False, **kw)
+
+    def _graph_and_inputs(self, points, xt, edge_index):
+        if edge_index is not None:
+            g = self.prepare_graph(edge_index, points.shape[0])
+            return g, points.reshape(-1, 2), xt.reshape(-1), None
+        if points.dim() != 3:
+            raise ValueError("dense mode expects points [B,V,2] and xt [B,V,V]")
+        B, V = points.shape[0], points.shape[1]
+        return self._dense_graph(B, V), points.reshape(-1, 2), xt.reshape(-1), (B, V, V)
+
+    def categorical_denoise_step(self, points, xt, t, device, edge_index=None, target_t=None, *,
+                                 uniform=None, return_aux=False):
+        g, pts, x, dense_shape = self._graph_and_inputs(points, xt, edge_index)
+        res = self._categorical(g, _lib.TASK_TSP, pts, x.float(), t, target_t, uniform, return_aux)
+        if dense_shape is None:
+            return res
+        if return_aux:
+            out, pred, prob = res
+            return out.reshape(dense_shape), pred.reshape(dense_shape + (2,)), prob.reshape(dense_shape)
+        return res.reshape(dense_shape)
+
+    def gaussian_denoise_step(self, points, xt, t, device, edge_index=None, target_t=None, *,
+                              noise=None, return_aux=False):
+        g, pts, x, dense_shape = self._graph_and_inputs(points, xt, edge_index)
+        res = self._gaussian(g, _lib.TASK_TSP, pts, x.float(), t, target_t, noise, return_aux)
+        if dense_shape is None:
+            return res
+        if return_aux:
+            out, pred = res
+            return out.reshape(dense_shape), pred.reshape(dense_shape)
+        return res.reshape(dense_shape)
+
+    def sample(self, points, edge_index=None, xt0=None, generator=None):
+        """The sampling loop of ``test_step`` (``pl_tsp_model.py:185-222``) for ONE noise sample per
+        graph of the call: returns the heatmap tensor (``+1e-6`` categorical, ``*0.5+0.5`` gaussian),
+        still on the device.  ``points``/``edge_index`` already hold the (possibly duplicated) batch."""
+        steps = self.args.inference_diffusion_steps
+        sched = InferenceSchedule(inference_schedule=self.args.inference_schedule, T=self.diffusion.T,
+                                  inference_T=steps)
+        if xt0 is None:
+            shape = (edge_index.shape[1],) if edge_index is not None else (points.shape[0], points.shape[1], points.shape[1])
+            xt0 = torch.randn(shape, generator=generator, device=self.device if generator is None else generator.device)
+        xt = xt0.to(self.device)
+        if self.diffusion_type == "categorical":
+            xt = (xt > 0).float()
+        for i in range(steps):
+            t1, t2 = sched(i)
+            t1, t2 = np.array([t1]).astype(int), np.array([t2]).astype(int)
+            if self.diffusion_type == "gaussian":
+                xt = self.gaussian_denoise_step(points, xt, t1, self.device, edge_index, target_t=t2)
+            else:
+                xt = self.categorical_denoise_step(points, xt, t1, self.device, edge_index, target_t=t2)
+        return xt * 0.5 + 0.5 if self.diffusion_type == "gaussian" else xt + 1e-6
+
+
+class MISModel(COMetaModel):
+    """Inference half of ``difusco/pl_mis_model.py`` (node features only)."""
+
+    def __init__(self, param_args=None, state_dict=None, **kw):
+        super().__init__(param_args=param_args, state_dict=state_dict, node_feature_only=True, **kw)
+
+    def categorical_denoise_step(self, xt, t, device, edge_index=None, target_t=None, *, uniform=None,
+                                 return_aux=False):
+        g = self.prepare_graph(edge_index, xt.reshape(-1).shape[0])
+        return self._categorical(g, _lib.TASK_MIS, None, xt.reshape(-1).float(), t, target_t, uniform, return_aux)
+
+    def gaussian_denoise_step(self, xt, t, device, edge_index=None, target_t=None, *, noise=None, return_aux=False):
+        g = self.prepare_graph(edge_index, xt.reshape(-1).shape[0])
+        return self._gaussian(g, _lib.TASK_MIS, None, xt.reshape(-1).float(), t, target_t, noise, return_aux)
+
+    def sample(self, n_nodes, edge_index, xt0=None, generator=None):
+        """``pl_mis_model.py:156-192`` for one noise sample per graph of the call."""
+        steps = self.args.inference_diffusion_steps
+        sched = InferenceSchedule(inference_schedule=self.args.inference_schedule, T=self.diffusion.T,
+                                  inference_T=steps)
+        if xt0 is None:
+            xt0 = torch.randn((n_nodes,), generator=generator, device=self.device if generator is None else generator.device)
+        xt = xt0.to(self.device)
+        if self.diffusion_type == "categorical":
+            xt = (xt > 0).float()
+        for i in range(steps):
+            t1, t2 = sched(i)
+            t1, t2 = np.array([t1]).astype(int), np.array([t2]).astype(int)
+            if self.diffusion_type == "gaussian":
+                xt = self.gaussian_denoise_step(xt, t1, self.device, edge_index, target_t=t2)
+            else:
+                xt = self.categorical_denoise_step(xt, t1, self.device, edge_index, target_t=t2)
+        return xt * 0.5 + 0.5 if self.diffusion_type == "gaussian" else xt + 1e-6

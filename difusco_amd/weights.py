@@ -1,0 +1,65 @@
+"""Packing of the reference ``GNNEncoder`` ``state_dict`` into the flat fp32 blob the kernels read.
+
+Key set (``difusco/models/gnn_encoder.py:303-347``), with or without the
+Lightning ``model.`` prefix.  Three constant tables are appended, computed here with the same torch
+CPU expressions the reference evaluates every forward pass (``models/nn.py:114-116``,
+``gnn_encoder.py:214-215,242-243``) so the device kernels use bit-identical frequencies.
+"""
+import math
+import re
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def strip_prefix(state, prefix="model."):
+    return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in state.items()}
+
+
+def infer_config(state):
+    state = strip_prefix(state)
+    hidden = int(state["node_embed.weight"].shape[0])
+    n_layers = 1 + max(int(m.group(1)) for m in (re.match(r"layers\.(\d+)\.", k) for k in state) if m)
+    out_channels = int(state["out.2.weight"].shape[0])
+    return hidden, n_layers, out_channels
+
+
+def constant_tables(hidden: int):
+    half = hidden // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+
+    def dim_t(n):
+        d = torch.arange(n, dtype=torch.float32)
+        return 10000 ** (2.0 * torch.div(d, 2, rounding_mode="trunc") / n)
+
+    return {"@time_freqs": freqs, "@dimt_pos": dim_t(half), "@dimt_scalar": dim_t(hidden)}
+
+
+def pack_state_dict(state) -> torch.Tensor:
+    """-> 1-D fp32 CPU tensor laid out per ``difusco_weights_layout``."""
+    state = {k: (v.detach().float().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v)).float())
+             for k, v in strip_prefix(state).items()}
+    hidden, n_layers, out_channels = infer_config(state)
+    offsets, total = _lib.weights_layout(hidden, n_layers, out_channels)
+    blob = torch.zeros(total, dtype=torch.float32)
+    consts = constant_tables(hidden)
+
+    def put(idx, tensor):
+        flat = tensor.reshape(-1)
+        blob[offsets[idx]: offsets[idx] + flat.numel()] = flat
+
+    for i, name in enumerate(_lib.W_GLOBAL):
+        put(i, consts[name] if name.startswith("@") else state[name])
+    for l in range(n_layers):
+        base = len(_lib.W_GLOBAL) + l * len(_lib.W_LAYER)
+        for i, name in enumerate(_lib.W_LAYER):
+            if name == "@node4.weight":      # rows U | V | A | B  -> one [4H, H] linear on node rows
+                t = torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0)
+            elif name == "@node4.bias":
+                t = torch.cat([state[f"layers.{l}.{m}.bias"] for m in "UVAB"], dim=0)
+            else:
+                t = state[name.format(l=l)]
+            put(base + i, t)
+    return blob

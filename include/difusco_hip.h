@@ -1,0 +1,183 @@
+/*
+ * difusco_hip.h - C ABI of the MI355X-native (gfx950) DIFUSCO denoise-step library.
+ *
+ * Drop-in boundary.  The reference has no FFI: its boundary is two Python methods,
+ *   TSPModel.categorical_denoise_step / gaussian_denoise_step   (difusco/pl_tsp_model.py:122-151)
+ *   MISModel.categorical_denoise_step / gaussian_denoise_step   (difusco/pl_mis_model.py:118-140)
+ * which call GNNEncoder.forward (difusco/models/gnn_encoder.py:452-462) and
+ * COMetaModel.categorical_posterior / gaussian_posterior (difusco/pl_meta_model.py:102-175).
+ * This header declares what a binding for that path needs: plain pointers and sizes, no torch types.
+ * All device pointers are HIP device memory of the current device; `stream` is a hipStream_t.
+ * Every function returns 0 on success, a negative DIFUSCO_E* code otherwise; difusco_last_error()
+ * gives the message of the calling thread's last failure.
+ *
+ * The binding a reference maintainer would add (ctypes) is shown in INTEGRATION.md; the in-tree
+ * Python host side is difusco_amd/ (same method names and argument meaning as the reference).
+ */
+#ifndef DIFUSCO_HIP_H
+#define DIFUSCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIFUSCO_ABI_VERSION 1
+
+enum {
+  DIFUSCO_OK = 0,
+  DIFUSCO_EINVAL = -1,      /* bad argument (shape, null pointer, unsupported hidden size ...) */
+  DIFUSCO_EWORKSPACE = -2,  /* workspace too small */
+  DIFUSCO_EHIP = -3,        /* a HIP runtime call failed */
+  DIFUSCO_EUNSUPPORTED = -4 /* e.g. aggregation other than "sum" (gnn_encoder.py:184-188) */
+};
+
+enum { DIFUSCO_TASK_TSP = 0, DIFUSCO_TASK_MIS = 1 };            /* edge features | node features only */
+enum { DIFUSCO_CATEGORICAL = 0, DIFUSCO_GAUSSIAN = 1 };
+enum {
+  DIFUSCO_RAND_NONE = 0,     /* no draw: categorical final step (target_t == 0) or DDIM */
+  DIFUSCO_RAND_INJECTED = 1, /* caller supplies uniforms (categorical) / normals (gaussian DDPM) */
+  DIFUSCO_RAND_PHILOX = 2    /* on-device Philox4x32-10 keyed by (seed, offset, element) */
+};
+
+int difusco_abi_version(void);
+const char* difusco_last_error(void);
+
+/* ---- weights ---------------------------------------------------------------------------------
+ * The packed fp32 blob holds every tensor of the reference GNNEncoder state_dict
+ * (gnn_encoder.py:303-347; key set in SURVEY.md section 5) plus three host-computed constant
+ * tables (timestep frequencies nn.py:114-116, the two `dim_t` vectors gnn_encoder.py:215,243).
+ * difusco_weights_layout() is the single source of truth for the offsets (in floats). */
+enum {
+  DIFUSCO_W_NODE_EMBED_W = 0, DIFUSCO_W_NODE_EMBED_B,
+  DIFUSCO_W_EDGE_EMBED_W, DIFUSCO_W_EDGE_EMBED_B,
+  DIFUSCO_W_TIME0_W, DIFUSCO_W_TIME0_B, DIFUSCO_W_TIME2_W, DIFUSCO_W_TIME2_B,
+  DIFUSCO_W_OUT_GN_W, DIFUSCO_W_OUT_GN_B, DIFUSCO_W_OUT_CONV_W, DIFUSCO_W_OUT_CONV_B,
+  DIFUSCO_W_TIME_FREQS,  /* [H/2]  exp(-ln(1e4) k/(H/2))                      */
+  DIFUSCO_W_DIMT_POS,    /* [H/2]  1e4^(2(k/2)/(H/2))  PositionEmbeddingSine   */
+  DIFUSCO_W_DIMT_SCALAR, /* [H]    1e4^(2(k/2)/H)      ScalarEmbeddingSine(1D) */
+  DIFUSCO_W_GLOBAL_COUNT
+};
+enum {                       /* per layer l, index = GLOBAL_COUNT + l*LAYER_COUNT + id */
+  DIFUSCO_WL_NODE4_W = 0,    /* [4H,H] rows: U | V | A | B  (gnn_encoder.py:52-55)  */
+  DIFUSCO_WL_NODE4_B,        /* [4H]                                                */
+  DIFUSCO_WL_C_W, DIFUSCO_WL_C_B,
+  DIFUSCO_WL_NORM_H_W, DIFUSCO_WL_NORM_H_B, DIFUSCO_WL_NORM_E_W, DIFUSCO_WL_NORM_E_B,
+  DIFUSCO_WL_TIME_W, DIFUSCO_WL_TIME_B,      /* time_embed_layers[l].1 : [H,H/2],[H] */
+  DIFUSCO_WL_OUT_LN_W, DIFUSCO_WL_OUT_LN_B,  /* per_layer_out[l].0                   */
+  DIFUSCO_WL_OUT_W, DIFUSCO_WL_OUT_B,        /* per_layer_out[l].2 : [H,H],[H]       */
+  DIFUSCO_WL_COUNT
+};
+/* Fills offsets[0 .. GLOBAL_COUNT + n_layers*WL_COUNT) (floats from blob start) and *total_floats.
+ * Returns the number of entries, or a negative error. */
+int difusco_weights_layout(int hidden, int n_layers, int out_channels,
+                           int64_t* offsets, int max_entries, int64_t* total_floats);
+
+/* ---- graph -----------------------------------------------------------------------------------
+ * HOST helper (no GPU needed): COO int64 edge list (2 x E, reference layout
+ * co_datasets/tsp_graph_dataset.py:53-62, mis_dataset.py:43-48, duplicate_edge_index
+ * pl_meta_model.py:177-184) -> CSR over the centre node edge_index[0], stable in the caller's edge
+ * order.  rowptr[n_nodes+1], col[E] (= edge_index[1] in CSR order), row[E], perm[E] (CSR slot ->
+ * caller edge id).  *identity = 1 when the input was already row-sorted (perm[s] == s). */
+int difusco_csr_from_coo_host(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes,
+                              int32_t* rowptr, int32_t* col, int32_t* row, int32_t* perm,
+                              int* identity);
+
+/* ---- the denoise step -------------------------------------------------------------------------- */
+typedef struct difusco_step_args {
+  uint32_t struct_size;   /* = sizeof(difusco_step_args), checked */
+  uint32_t abi_version;   /* = DIFUSCO_ABI_VERSION */
+
+  /* model */
+  int32_t hidden;         /* 64 | 128 | 256 (reference default 256, train.py:50) */
+  int32_t n_layers;
+  int32_t out_channels;   /* 2 categorical | 1 gaussian (pl_meta_model.py:28-35) */
+  int32_t task;           /* DIFUSCO_TASK_* */
+  const float* weights;   /* device, packed per difusco_weights_layout */
+
+  /* graph: disjoint union of the graphs of this call, CSR over centre node (device) */
+  int32_t n_nodes, n_edges;
+  const int32_t* rowptr;  /* [n_nodes+1] */
+  const int32_t* col;     /* [n_edges] */
+  const int32_t* perm;    /* [n_edges] CSR slot -> caller edge id, or NULL (identity) */
+  /* statistic segments of the head GroupNorm over output rows (edges for TSP, nodes for MIS), in
+   * CSR-slot / node order.  n_segments = 1, seg_ptr = {0, rows} reproduces the reference's sparse
+   * call (one statistic over ALL graphs of the call, gnn_encoder.py:400-401); one
+   * segment per graph reproduces the dense path (gnn_encoder.py:380).  Device pointer; may be
+   * NULL when n_segments == 1. */
+  int32_t n_segments;
+  const int32_t* seg_ptr; /* device, [n_segments+1] */
+
+  /* inputs (device) */
+  const float* points;    /* [n_nodes,2]  TSP only */
+  const float* xt;        /* TSP: [n_edges] caller edge order;  MIS: [n_nodes] */
+  float t;                /* diffusion time t (shared by the whole call, pl_tsp_model.py:124) */
+  int32_t xt_is_binary;   /* 1: xt is exactly 0/1 (categorical inference): 2-row embedding table */
+
+  /* posterior */
+  int32_t diffusion;      /* DIFUSCO_CATEGORICAL | DIFUSCO_GAUSSIAN */
+  /* categorical: post[0..3] = c0[xt=0], c0[xt=1], c1[xt=0], c1[xt=1] with
+   *   p(x_s=1) = c0[xt]*p0 + c1[xt]*p1   (pl_meta_model.py:125-137; host computes them in fp32)
+   *   post[4] = 1 if target_t > 0 (Bernoulli draw) else 0 (clamp(min=0), :139-142)
+   * gaussian : x_s = post[0]*(xt - post[1]*pred) + post[2]*pred + post[3]*z  (:161-172) */
+  float post[8];
+  int32_t rand_mode;      /* DIFUSCO_RAND_* */
+  const float* rand;      /* injected uniforms / normals, caller order, or NULL */
+  uint64_t seed, offset;  /* Philox key / per-call offset */
+
+  /* outputs (device) */
+  float* xt_out;          /* same shape/order as xt */
+  float* pred_out;        /* optional: logits [rows,2] (categorical) or eps [rows] (gaussian) */
+  float* prob_out;        /* optional, categorical: p(x_s=1) before clamping/sampling, [rows] */
+
+  void* workspace;        /* device, >= difusco_workspace_bytes(...) */
+  size_t workspace_bytes;
+  void* stream;           /* hipStream_t */
+} difusco_step_args;
+
+size_t difusco_workspace_bytes(int hidden, int n_layers, int n_nodes, int n_edges, int n_segments);
+
+/* One reverse-diffusion step: GNN denoiser forward + posterior (+ sample).  Asynchronous on
+ * args->stream.  Replaces {categorical,gaussian}_denoise_step of pl_tsp_model.py / pl_mis_model.py. */
+int difusco_denoise_step(const difusco_step_args* args);
+
+/* ---- single kernels, exported for parity tests and profiling ------------------------------------ */
+/* Y[m, ldy] (cols [0,n_out)) = X[m,k] * W[n_out,k]^T + bias (+ residual, same layout as Y).
+ * k in {32,64,128,256}; n_out multiple of 32.  fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+int difusco_linear_rows(const float* x, const float* w, const float* bias, const float* residual,
+                        float* y, int64_t m, int k, int n_out, int64_t ldy, void* stream);
+
+/* One gated-GCN message-passing pass (gnn_encoder.py:110-135 + :445-448 + per_layer_out LN/SiLU):
+ *   e' = Ah[j]+Bh[i]+Ce ; h[i] += ReLU(LN_h(Uh[i] + sum_j sigmoid(e')*Vh[j])) (+tbias, MIS)
+ *   ce_act[s] <- SiLU(LN_o(ReLU(LN_e(e')) (+tbias, TSP)))      (in place over Ce)
+ * node4 = [n_nodes,4H] rows U|V|A|B.  ln = {norm_h w,b, norm_e w,b, out_ln w,b} device pointers. */
+int difusco_edge_gate_aggregate(int hidden, int n_nodes, const int32_t* rowptr, const int32_t* col,
+                                const float* node4, float* ce_act, float* h,
+                                const float* norm_h_w, const float* norm_h_b,
+                                const float* norm_e_w, const float* norm_e_b,
+                                const float* out_ln_w, const float* out_ln_b,
+                                const float* tbias, int time_on_edge, void* stream);
+
+/* Elementwise posteriors on already computed predictions (pl_meta_model.py:102-175). */
+int difusco_categorical_posterior(const float* logits, const float* xt, const float* post,
+                                  int rand_mode, const float* rand, uint64_t seed, uint64_t offset,
+                                  float* xt_out, float* prob_out, int64_t n, void* stream);
+int difusco_gaussian_posterior(const float* pred, const float* xt, const float* post,
+                               int rand_mode, const float* rand, uint64_t seed, uint64_t offset,
+                               float* xt_out, int64_t n, void* stream);
+
+/* ---- in-library profiler (bench.py): HIP events on the launch stream around every kernel launch of
+ * difusco_denoise_step, summed per category.  Categories: 0 edge-row linear (rows = n_edges),
+ * 1 node-row linear, 2 edge gate/aggregate, 3 head (GroupNorm+conv+posterior, 3 launches),
+ * 4 embeddings / time features / memset.  enable(1, max) (re)arms and pre-creates the events;
+ * collect() synchronises, fills ms[c] / launches[c] for c < 5, re-arms, returns brackets read. */
+#define DIFUSCO_PROFILE_CATEGORIES 5
+int difusco_profile_enable(int on, int max_launches);
+int difusco_profile_collect(double* ms, int64_t* launches, int n_categories);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFUSCO_HIP_H */

@@ -1,0 +1,79 @@
+"""CPU tests of the multi-GPU plumbing: graph sharding and the one-off weight broadcast, exercised with
+world_size 2 over gloo (the GPU path uses the same code over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from difusco_amd import synthetic
+from difusco_amd.dist import broadcast_weights, shard_range
+from oracle import difusco_oracle as O
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 8, 64, 65, 128):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_generators_match_oracle():
+    for (n, k, seed) in [(50, 6, 1), (200, 20, 7)]:
+        p1, e1 = synthetic.tsp_instance(n, k, seed)
+        p2, e2 = O.tsp_instance(n, k, seed)
+        np.testing.assert_array_equal(p1, p2)
+        np.testing.assert_array_equal(e1, e2)
+    np.testing.assert_array_equal(synthetic.er_mis_edge_index(60, 0.2, 3), O.er_mis_instance(60, 0.2, 3))
+    a, b = synthetic.random_state_dict(64, 2, 2, 5), O.init_params(64, 2, 2, 5)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    pts, ei = synthetic.tsp_batch(30, 5, [0, 1, 2])
+    assert pts.shape == (90, 2) and ei.shape == (2, 450)
+    assert ei[:, 150:300].min() >= 30 and ei[:, 150:300].max() < 60      # disjoint union, ids offset
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sd = synthetic.random_state_dict(64, 2, 2, seed=11) if rank == 0 else None
+        cfg, blob = broadcast_weights(sd, torch.device("cpu"), src=0)
+        lo, hi = shard_range(5, rank, world)
+        # every rank builds ITS graphs only; no collective is needed afterwards
+        pts, ei = synthetic.tsp_batch(20, 4, range(lo, hi))
+        ret[rank] = (cfg, float(blob.double().sum()), blob.numel(), (lo, hi), tuple(pts.shape), tuple(ei.shape))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_and_shard_two_processes():
+    from difusco_amd.weights import pack_state_dict
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        ret = dict(ret)
+    ref = pack_state_dict(synthetic.random_state_dict(64, 2, 2, seed=11))
+    assert ret[0][0] == ret[1][0] == (64, 2, 2)
+    assert ret[0][2] == ret[1][2] == ref.numel()
+    assert ret[0][1] == ret[1][1] == float(ref.double().sum())
+    assert ret[0][3] == (0, 3) and ret[1][3] == (3, 5)
+    assert ret[0][4] == (60, 2) and ret[1][4] == (40, 2)

@@ -1,0 +1,431 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs and against the committed golden fixtures.
+
+Tolerances (fp32 path): network outputs 1e-4 absolute (north_star bound; observed values are printed),
+posterior probabilities 1e-4, sampled bits identical for identical uniforms away from ties
+(|u - p| > 1e-4)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import difusco_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from difusco_amd import _lib
+    return _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------
+# single kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,k,n_out", [(1, 256, 256), (2, 64, 64), (127, 256, 256), (128, 256, 256),
+                                       (129, 128, 128), (1000, 256, 1024), (517, 64, 256), (300, 32, 32),
+                                       (4099, 256, 256), (333, 128, 512), (65, 64, 96)])
+def test_linear_rows(dev, L, m, k, n_out):
+    g = torch.Generator().manual_seed(m * 7 + k + n_out)
+    x = torch.randn(m, k, generator=g)
+    # asymmetric, non-square weight so that a transposed operand or output cannot pass
+    w = torch.randn(n_out, k, generator=g) / np.sqrt(k) + torch.arange(n_out).float()[:, None] * 1e-3
+    b = torch.randn(n_out, generator=g)
+    r = torch.randn(m, n_out, generator=g)
+    ref = (x.double() @ w.double().t() + b.double() + r.double())
+    y = torch.full((m, n_out), float("nan"), device=dev)
+    L.check(L.lib().difusco_linear_rows(_p(x.to(dev)), _p(w.to(dev)), _p(b.to(dev)), _p(r.to(dev)), _p(y),
+                                        m, k, n_out, n_out, _stream()))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-6 * max(scale, 1.0) * np.sqrt(k), (err, scale)
+    # no bias / no residual, strided output (ldy > n_out), untouched padding columns
+    y2 = torch.full((m, n_out + 32), 7.0, device=dev)
+    L.check(L.lib().difusco_linear_rows(_p(x.to(dev)), _p(w.to(dev)), None, None, _p(y2), m, k, n_out, n_out + 32, _stream()))
+    torch.cuda.synchronize()
+    ref2 = x.double() @ w.double().t()
+    assert (y2[:, :n_out].cpu().double() - ref2).abs().max().item() <= 2e-6 * max(scale, 1.0) * np.sqrt(k)
+    assert (y2[:, n_out:] == 7.0).all()
+
+
+def test_linear_rows_in_place_residual(dev, L):
+    g = torch.Generator().manual_seed(5)
+    m, k = 700, 256
+    x, w, b = torch.randn(m, k, generator=g), torch.randn(k, k, generator=g) / 16, torch.randn(k, generator=g)
+    e = torch.randn(m, k, generator=g)
+    ref = e.double() + x.double() @ w.double().t() + b.double()
+    ed = e.to(dev)
+    L.check(L.lib().difusco_linear_rows(_p(x.to(dev)), _p(w.to(dev)), _p(b.to(dev)), _p(ed), _p(ed), m, k, k, k, _stream()))
+    torch.cuda.synchronize()
+    assert (ed.cpu().double() - ref).abs().max().item() < 5e-5
+
+
+def test_linear_rows_rejects_bad_shapes(L, dev):
+    x = torch.zeros(4, 100, device=dev)
+    assert L.lib().difusco_linear_rows(_p(x), _p(x), None, None, _p(x), 4, 100, 64, 64, _stream()) == -1
+    assert L.lib().difusco_linear_rows(_p(x), _p(x), None, None, _p(x), 4, 64, 48, 48, _stream()) == -1
+
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+@pytest.mark.parametrize("time_on_edge", [1, 0])
+def test_edge_gate_aggregate(dev, L, H, time_on_edge):
+    """One message-passing pass against the oracle's layer arithmetic (gnn_encoder.py:110-135,445-448)."""
+    import torch.nn.functional as F
+    from difusco_amd import graph
+    g = torch.Generator().manual_seed(H + time_on_edge)
+    n = 37
+    ei = O.er_mis_instance(n, 0.25, seed=H)
+    ei = ei[:, ei[0] != 5]                       # an empty row
+    rowptr, col, row, perm, _ = graph.csr_from_coo_host(ei, n)
+    E = col.shape[0]
+    node4 = torch.randn(n, 4 * H, generator=g)
+    ce = torch.randn(E, H, generator=g)
+    h = torch.randn(n, H, generator=g)
+    prm = [1 + 0.1 * torch.randn(H, generator=g) if i % 2 == 0 else 0.1 * torch.randn(H, generator=g) for i in range(6)]
+    tb = torch.randn(H, generator=g)
+    rowt, colt = torch.from_numpy(row).long(), torch.from_numpy(col).long()
+    Uh, Vh, Ah, Bh = node4[:, :H], node4[:, H:2 * H], node4[:, 2 * H:3 * H], node4[:, 3 * H:]
+    e1 = Ah[colt] + Bh[rowt] + ce
+    agg = O.segment_sum(torch.sigmoid(e1) * Vh[colt], rowt, n)
+    hn = F.relu(F.layer_norm(Uh + agg, (H,), prm[0], prm[1], 1e-5))
+    en = F.relu(F.layer_norm(e1, (H,), prm[2], prm[3], 1e-5))
+    if time_on_edge:
+        en = en + tb
+    else:
+        hn = hn + tb
+    h_ref = h + hn
+    act_ref = F.silu(F.layer_norm(en, (H,), prm[4], prm[5], 1e-5))
+
+    d = lambda t: t.to(dev).contiguous()
+    ce_d, h_d = d(ce), d(h)
+    prm_d = [d(t) for t in prm]
+    tb_d, n4_d = d(tb), d(node4)
+    rp_d, col_d = d(torch.from_numpy(rowptr)), d(torch.from_numpy(col))
+    L.check(L.lib().difusco_edge_gate_aggregate(H, n, _p(rp_d), _p(col_d), _p(n4_d), _p(ce_d), _p(h_d),
+                                                *[_p(t) for t in prm_d], _p(tb_d), time_on_edge, _stream()))
+    torch.cuda.synchronize()
+    assert (h_d.cpu() - h_ref).abs().max().item() < 2e-5
+    assert (ce_d.cpu() - act_ref).abs().max().item() < 2e-5
+
+
+def test_posterior_kernels(dev, L, golden_dir):
+    from difusco_amd import schedules
+    z = np.load(os.path.join(golden_dir, "posteriors.npz"))
+    cd, gd = schedules.CategoricalDiffusion(1000, "linear"), schedules.GaussianDiffusion(1000, "linear")
+    for i in range(6):
+        t, tt = (int(v) for v in z[f"cat{i}_t"])
+        tt = t - 1 if tt < 0 else tt
+        post = np.zeros(8, dtype=np.float32)
+        post[:4] = cd.posterior_constants(t, tt)
+        post[4] = 1.0 if tt > 0 else 0.0
+        x0 = torch.from_numpy(z[f"cat{i}_x0"]).reshape(-1, 2)
+        logits = x0.log().to(dev).contiguous()
+        xt = torch.from_numpy(z[f"cat{i}_xt"]).float().to(dev)
+        n = xt.numel()
+        out = torch.empty(n, device=dev)
+        prob = torch.empty(n, device=dev)
+        u = torch.from_numpy(z[f"cat{i}_uniform"]).reshape(-1).to(dev) if tt > 0 else None
+        L.check(L.lib().difusco_categorical_posterior(
+            _p(logits), _p(xt), post.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 1 if tt > 0 else 0, _p(u), 0, 0,
+            _p(out), _p(prob), n, _stream()))
+        torch.cuda.synchronize()
+        if tt > 0:
+            ref_p = z[f"cat{i}_prob"].reshape(-1)
+            np.testing.assert_allclose(prob.cpu().numpy(), ref_p, rtol=0, atol=1e-6)
+            safe = np.abs(z[f"cat{i}_uniform"].reshape(-1) - ref_p) > 1e-5
+            np.testing.assert_array_equal(out.cpu().numpy()[safe], z[f"cat{i}_out"].reshape(-1)[safe])
+        else:
+            np.testing.assert_allclose(out.cpu().numpy(), z[f"cat{i}_out"].reshape(-1), rtol=0, atol=1e-6)
+    for i in range(5):
+        t, tt = (int(v) for v in z[f"gau{i}_t"])
+        trick = "ddim" if int(z[f"gau{i}_trick"]) else None
+        post = np.zeros(8, dtype=np.float32)
+        post[:5] = gd.posterior_constants(t, tt, trick)
+        pred, xt = torch.from_numpy(z[f"gau{i}_pred"]).to(dev), torch.from_numpy(z[f"gau{i}_xt"]).to(dev)
+        noise = torch.from_numpy(z[f"gau{i}_noise"]).to(dev) if post[4] else None
+        out = torch.empty_like(xt)
+        L.check(L.lib().difusco_gaussian_posterior(
+            _p(pred), _p(xt), post.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 1 if post[4] else 0, _p(noise), 0, 0,
+            _p(out), xt.numel(), _stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), z[f"gau{i}_out"], rtol=0, atol=5e-7)
+
+
+def test_philox_bernoulli_statistics(dev, L):
+    """On-device Philox draws: frequencies match p, different offsets give different streams, same
+    (seed, offset) is reproducible."""
+    n = 1 << 20
+    p = torch.rand(n, generator=torch.Generator().manual_seed(1))
+    x0 = torch.stack([1 - p, p], dim=1).clamp_min(1e-12)
+    logits = x0.log().to(dev).contiguous()
+    xt = torch.zeros(n, device=dev)
+    post = np.array([0, 0, 1, 1, 1, 0, 0, 0], dtype=np.float32)      # prob = p1 exactly
+    outs = []
+    for seed, off in [(11, 0), (11, 0), (11, 1), (12, 0)]:
+        out = torch.empty(n, device=dev)
+        L.check(L.lib().difusco_categorical_posterior(
+            _p(logits), _p(xt), post.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 2, None, seed, off, _p(out), None, n, _stream()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[3])
+    assert set(outs[0].unique().tolist()) <= {0.0, 1.0}
+    assert abs(outs[0].mean().item() - p.mean().item()) < 2e-3
+    for lo in np.arange(0, 1, 0.1):
+        sel = (p >= lo) & (p < lo + 0.1)
+        assert abs(outs[0][sel].mean().item() - p[sel].mean().item()) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# whole denoise steps against the golden fixtures (reference-generated) and the oracle
+# ------------------------------------------------------------------------------------------------
+def _golden_weights(golden_dir):
+    z = np.load(os.path.join(golden_dir, "weights_h64_l2.npz"))
+    cat = {k: torch.from_numpy(z[k]) for k in z.files if k != "provenance" and not k.startswith("gaussian_")}
+    gau = dict(cat)
+    for k in z.files:
+        if k.startswith("gaussian_"):
+            gau[k[len("gaussian_"):]] = torch.from_numpy(z[k])
+    return cat, gau
+
+
+def _args(kind, sparse_factor=8, trick="ddim", H=64, L=2):
+    return dict(diffusion_type=kind, diffusion_schedule="linear", diffusion_steps=1000, sparse_factor=sparse_factor,
+                n_layers=L, hidden_dim=H, inference_trick=trick)
+
+
+def _check_cat(z, i, out, logits, prob, order=None):
+    t, tt = (int(v) for v in z[f"cat{i}_t"])
+    ref_logits = z[f"cat{i}_logits"]
+    if ref_logits.ndim == 4:                                   # dense fixture: [B,C,V,V] -> [B,V,V,C]
+        ref_logits = np.transpose(ref_logits, (0, 2, 3, 1))
+    err = np.abs(logits.cpu().numpy().reshape(ref_logits.shape) - ref_logits).max()
+    assert err < TOL, f"logits L_inf {err}"
+    if tt > 0:
+        ref_p = z[f"cat{i}_prob"].reshape(-1)
+        assert np.abs(prob.cpu().numpy().reshape(-1) - ref_p).max() < TOL
+        safe = np.abs(z[f"cat{i}_uniform"].reshape(-1) - ref_p) > 1e-4
+        np.testing.assert_array_equal(out.cpu().numpy().reshape(-1)[safe], z[f"cat{i}_out"].reshape(-1)[safe])
+    else:
+        assert np.abs(out.cpu().numpy().reshape(-1) - z[f"cat{i}_out"].reshape(-1)).max() < TOL
+    return err
+
+
+@pytest.mark.parametrize("G", [1, 3])
+def test_golden_tsp_sparse(dev, golden_dir, G):
+    from difusco_amd import TSPModel
+    z = np.load(os.path.join(golden_dir, f"tsp_sparse_h64_l2_g{G}.npz"))
+    cat, gau = _golden_weights(golden_dir)
+    pts, ei = torch.from_numpy(z["points"]).to(dev), torch.from_numpy(z["edge_index"]).to(dev)
+    m = TSPModel(_args("categorical"), cat, device=dev)
+    for i in range(4):
+        t, tt = z[f"cat{i}_t"]
+        u = torch.from_numpy(z[f"cat{i}_uniform"]).reshape(-1) if f"cat{i}_uniform" in z.files else None
+        out, logits, prob = m.categorical_denoise_step(pts, torch.from_numpy(z[f"cat{i}_xt"]).to(dev), np.array([t]), dev,
+                                                       ei, target_t=np.array([tt]), uniform=u, return_aux=True)
+        assert out.shape == (ei.shape[1],) and out.dtype == torch.float32 and out.device.type == "cuda"
+        _check_cat(z, i, out, logits, prob)
+    mg = TSPModel(_args("gaussian"), gau, device=dev)
+    for i in range(2):
+        t, tt = z[f"gau{i}_t"]
+        noise = torch.from_numpy(z[f"gau{i}_noise"]) if f"gau{i}_noise" in z.files else None
+        out, pred = mg.gaussian_denoise_step(pts, torch.from_numpy(z[f"gau{i}_xt"]).to(dev), np.array([t]), dev, ei,
+                                             target_t=np.array([tt]), noise=noise, return_aux=True)
+        assert np.abs(pred.cpu().numpy() - z[f"gau{i}_pred"].squeeze(1)).max() < TOL
+        assert np.abs(out.cpu().numpy() - z[f"gau{i}_out"]).max() < TOL
+
+
+def test_golden_tsp_dense(dev, golden_dir):
+    """configs[0] family: dense TSP (pure reference arithmetic in the fixture)."""
+    from difusco_amd import TSPModel
+    z = np.load(os.path.join(golden_dir, "tsp_dense_h64_l2.npz"))
+    cat, gau = _golden_weights(golden_dir)
+    pts = torch.from_numpy(z["points"]).to(dev)
+    m = TSPModel(_args("categorical", sparse_factor=-1), cat, device=dev)
+    for i in range(3):
+        t, tt = z[f"cat{i}_t"]
+        u = torch.from_numpy(z[f"cat{i}_uniform"]) if f"cat{i}_uniform" in z.files else None
+        out, logits, prob = m.categorical_denoise_step(pts, torch.from_numpy(z[f"cat{i}_xt"]).to(dev), np.array([t]), dev,
+                                                       None, target_t=np.array([tt]), uniform=u, return_aux=True)
+        assert tuple(out.shape) == z[f"cat{i}_xt"].shape
+        _check_cat(z, i, out, logits, prob)
+    mg = TSPModel(_args("gaussian", sparse_factor=-1), gau, device=dev)
+    for i in range(2):
+        t, tt = z[f"gau{i}_t"]
+        noise = torch.from_numpy(z[f"gau{i}_noise"]) if f"gau{i}_noise" in z.files else None
+        out, pred = mg.gaussian_denoise_step(pts, torch.from_numpy(z[f"gau{i}_xt"]).to(dev), np.array([t]), dev, None,
+                                             target_t=np.array([tt]), noise=noise, return_aux=True)
+        assert np.abs(pred.cpu().numpy() - z[f"gau{i}_pred"].squeeze(1)).max() < TOL
+        assert np.abs(out.cpu().numpy() - z[f"gau{i}_out"]).max() < TOL
+
+
+def test_golden_mis(dev, golden_dir):
+    from difusco_amd import MISModel
+    z = np.load(os.path.join(golden_dir, "mis_sparse_h64_l2.npz"))
+    cat, gau = _golden_weights(golden_dir)
+    ei = torch.from_numpy(z["edge_index"]).to(dev)
+    m = MISModel(_args("categorical", sparse_factor=-1), cat, device=dev)
+    for i in range(3):
+        t, tt = z[f"cat{i}_t"]
+        u = torch.from_numpy(z[f"cat{i}_uniform"]).reshape(-1) if f"cat{i}_uniform" in z.files else None
+        out, logits, prob = m.categorical_denoise_step(torch.from_numpy(z[f"cat{i}_xt"]).to(dev), np.array([t]), dev, ei,
+                                                       target_t=np.array([tt]), uniform=u, return_aux=True)
+        _check_cat(z, i, out, logits, prob)
+    mg = MISModel(_args("gaussian", sparse_factor=-1), gau, device=dev)
+    for i in range(2):
+        t, tt = z[f"gau{i}_t"]
+        noise = torch.from_numpy(z[f"gau{i}_noise"]) if f"gau{i}_noise" in z.files else None
+        out, pred = mg.gaussian_denoise_step(torch.from_numpy(z[f"gau{i}_xt"]).to(dev), np.array([t]), dev, ei,
+                                             target_t=np.array([tt]), noise=noise, return_aux=True)
+        assert np.abs(pred.cpu().numpy() - z[f"gau{i}_pred"].squeeze(1)).max() < TOL
+        assert np.abs(out.cpu().numpy() - z[f"gau{i}_out"]).max() < TOL
+
+
+@pytest.mark.parametrize("H,Lyr,N,K,G", [(256, 3, 60, 10, 2), (256, 12, 100, 20, 1), (128, 2, 33, 5, 3)])
+def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G):
+    """H=256 / 12 layers (the production width) against the oracle on seeded synthetic inputs,
+    teacher-forced, plus shuffled (non row-sorted) edge order through the perm path."""
+    from difusco_amd import TSPModel
+    p = O.init_params(H, Lyr, 2, seed=H + N)
+    pts1, ei1 = O.tsp_instance(N, K, seed=N)
+    pts = torch.from_numpy(np.tile(pts1, (G, 1)))
+    ei = O.duplicate_edge_index(torch.from_numpy(ei1), N, G)
+    g = torch.Generator().manual_seed(9)
+    xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
+    u = torch.rand(ei.shape[1], generator=g)
+    tab = O.CategoricalTables()
+    m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev)
+    for (t, tt) in [(1000, 969), (57, 31), (1, 0)]:
+        ref_out, ref_logits, ref_prob = O.tsp_categorical_denoise_step(p, tab, pts, xt, t, ei, tt, uniform=u, return_aux=True)
+        out, logits, prob = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev),
+                                                       target_t=np.array([tt]), uniform=u, return_aux=True)
+        e_log = (logits.cpu() - ref_logits).abs().max().item()
+        e_prob = (prob.cpu() - ref_prob.reshape(-1)).abs().max().item()
+        print(f"H={H} L={Lyr} t={t}: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
+        assert e_log < TOL and e_prob < TOL
+        if tt > 0:
+            safe = (u - ref_prob.reshape(-1)).abs() > 1e-4
+            assert torch.equal(out.cpu()[safe], ref_out[safe])
+        else:
+            assert (out.cpu() - ref_out).abs().max().item() < TOL
+    # shuffled caller edge order: outputs must follow the caller's order
+    perm = torch.randperm(ei.shape[1], generator=g)
+    ei_s, xt_s, u_s = ei[:, perm], xt[perm], u[perm]
+    ref_out, ref_logits, ref_prob = O.tsp_categorical_denoise_step(p, tab, pts, xt_s, 500, ei_s, 400, uniform=u_s, return_aux=True)
+    out, logits, prob = m.categorical_denoise_step(pts.to(dev), xt_s.to(dev), np.array([500]), dev, ei_s.to(dev),
+                                                   target_t=np.array([400]), uniform=u_s, return_aux=True)
+    assert (logits.cpu() - ref_logits).abs().max().item() < TOL
+    safe = (u_s - ref_prob.reshape(-1)).abs() > 1e-4
+    assert torch.equal(out.cpu()[safe], ref_out[safe])
+
+
+def test_oracle_tsp_gaussian_full_width(dev):
+    from difusco_amd import TSPModel
+    H, Lyr, N, K = 256, 4, 80, 12
+    p = O.init_params(H, Lyr, 1, seed=77)
+    pts, ei = O.tsp_instance(N, K, seed=5)
+    pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
+    g = torch.Generator().manual_seed(3)
+    xt = torch.randn(ei.shape[1], generator=g)
+    z = torch.randn(ei.shape[1], generator=g)
+    tab = O.GaussianTables()
+    for trick, steps in [("ddim", [(1000, 969), (1, 0)]), (None, [(700, 699)])]:
+        m = TSPModel(_args("gaussian", K, trick=trick, H=H, L=Lyr), p, device=dev)
+        for (t, tt) in steps:
+            ref_out, ref_pred = O.tsp_gaussian_denoise_step(p, tab, pts, xt, t, ei, tt, inference_trick=trick, noise=z, return_aux=True)
+            out, pred = m.gaussian_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev), target_t=np.array([tt]),
+                                                noise=z, return_aux=True)
+            assert (pred.cpu() - ref_pred).abs().max().item() < TOL
+            assert (out.cpu() - ref_out).abs().max().item() < TOL
+
+
+def test_oracle_mis_full_width(dev):
+    from difusco_amd import MISModel
+    H, Lyr, n = 256, 4, 120
+    p = O.init_params(H, Lyr, 2, seed=8)
+    ei = torch.from_numpy(O.er_mis_instance(n, 0.15, seed=4))
+    g = torch.Generator().manual_seed(2)
+    xt = (torch.randn(n, generator=g) > 0).float()
+    u = torch.rand(n, generator=g)
+    tab = O.CategoricalTables()
+    m = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev)
+    for (t, tt) in [(1000, 969), (1, 0)]:
+        ref_out, ref_logits, ref_prob = O.mis_categorical_denoise_step(p, tab, xt, t, ei, tt, uniform=u, return_aux=True)
+        out, logits, prob = m.categorical_denoise_step(xt.to(dev), np.array([t]), dev, ei.to(dev), target_t=np.array([tt]),
+                                                       uniform=u, return_aux=True)
+        assert (logits.cpu() - ref_logits).abs().max().item() < TOL
+        assert (prob.cpu() - ref_prob.reshape(-1)).abs().max().item() < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE.json sizes (too big for the oracle in seconds)
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties_tsp500(dev):
+    """TSP-500 / K=50 / H=256 / 12 layers, 4 graphs: (1) bitwise determinism, (2) replicas of one graph
+    in a batch with per-graph statistic segments give bitwise identical rows, (3) a batch equals its
+    graphs run alone when the statistics are per graph, (4) outputs are {0,1} and finite."""
+    from difusco_amd import TSPModel, _lib
+    from difusco_amd.graph import build_csr
+    H, Lyr, N, K, G = 256, 12, 500, 50, 4
+    p = O.init_params(H, Lyr, 2, seed=1)
+    pts1, ei1 = O.tsp_instance(N, K, seed=123)
+    pts = torch.from_numpy(np.tile(pts1, (G, 1))).to(dev)
+    ei = O.duplicate_edge_index(torch.from_numpy(ei1), N, G).to(dev)
+    E1 = ei1.shape[1]
+    g = torch.Generator().manual_seed(4)
+    xt1 = (torch.randn(E1, generator=g) > 0).float()
+    u1 = torch.rand(E1, generator=g)
+    xt, u = xt1.repeat(G).to(dev), u1.repeat(G)
+    m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev)
+    a, la, pa = m.categorical_denoise_step(pts, xt, np.array([500]), dev, ei, target_t=np.array([450]), uniform=u, return_aux=True)
+    b, lb, pb = m.categorical_denoise_step(pts, xt, np.array([500]), dev, ei, target_t=np.array([450]), uniform=u, return_aux=True)
+    assert torch.equal(a, b) and torch.equal(la, lb)
+    assert torch.isfinite(la).all() and set(a.unique().tolist()) <= {0.0, 1.0}
+    # per-graph statistic segments
+    seg = np.arange(G + 1) * E1
+    gseg = build_csr(ei, N * G, dev, seg_rows=seg)
+    post = np.zeros(8, dtype=np.float32)
+    post[:4] = m.diffusion.posterior_constants(500, 450)
+    post[4] = 1.0
+    o_seg, l_seg, _ = m.model.step(gseg, _lib.TASK_TSP, _lib.CATEGORICAL, xt, 500.0, post, points=pts, xt_is_binary=True,
+                                   rand=u, want_pred=True, want_prob=True)
+    l_seg = l_seg.reshape(G, E1, 2)
+    for k in range(1, G):
+        assert torch.equal(l_seg[0], l_seg[k])
+    one, l_one, _ = m.categorical_denoise_step(torch.from_numpy(pts1).to(dev), xt1.to(dev), np.array([500]), dev,
+                                               torch.from_numpy(ei1).to(dev), target_t=np.array([450]), uniform=u1, return_aux=True)
+    assert torch.equal(l_one, l_seg[0])
+    assert torch.equal(one, o_seg[:E1])
+
+
+def test_sampling_loop_runs(dev):
+    """The 50-step loop end to end (pl_tsp_model.py:185-222) on a small graph with on-device Philox."""
+    from difusco_amd import TSPModel
+    p = O.init_params(64, 2, 2, seed=0)
+    pts, ei = O.tsp_instance(40, 8, seed=0)
+    a = dict(_args("categorical", 8), inference_diffusion_steps=50, inference_schedule="cosine")
+    m = TSPModel(a, p, device=dev, seed=5)
+    heat = m.sample(torch.from_numpy(pts).to(dev), torch.from_numpy(ei).to(dev))
+    assert heat.shape == (ei.shape[1],) and torch.isfinite(heat).all()
+    assert heat.min().item() >= 1e-6 - 1e-9 and heat.max().item() <= 1.0 + 2e-6
