@@ -54,15 +54,15 @@ def test_linear_rows(dev, L, m, k, n_out):
     r = torch.randn(m, n_out, generator=g)
     ref = (x.double() @ w.double().t() + b.double() + r.double())
     y = torch.full((m, n_out), float("nan"), device=dev)
-    L.check(L.lib().difusco_linear_rows(_p(x.to(dev)), _p(w.to(dev)), _p(b.to(dev)), _p(r.to(dev)), _p(y),
-                                        m, k, n_out, n_out, _stream()))
+    xd, wd, bd, rd = x.to(dev), w.to(dev), b.to(dev), r.to(dev)   # keep alive: only raw pointers cross the ABI
+    L.check(L.lib().difusco_linear_rows(_p(xd), _p(wd), _p(bd), _p(rd), _p(y), m, k, n_out, n_out, _stream()))
     torch.cuda.synchronize()
     err = (y.cpu().double() - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= 2e-6 * max(scale, 1.0) * np.sqrt(k), (err, scale)
     # no bias / no residual, strided output (ldy > n_out), untouched padding columns
     y2 = torch.full((m, n_out + 32), 7.0, device=dev)
-    L.check(L.lib().difusco_linear_rows(_p(x.to(dev)), _p(w.to(dev)), None, None, _p(y2), m, k, n_out, n_out + 32, _stream()))
+    L.check(L.lib().difusco_linear_rows(_p(xd), _p(wd), None, None, _p(y2), m, k, n_out, n_out + 32, _stream()))
     torch.cuda.synchronize()
     ref2 = x.double() @ w.double().t()
     assert (y2[:, :n_out].cpu().double() - ref2).abs().max().item() <= 2e-6 * max(scale, 1.0) * np.sqrt(k)
@@ -75,8 +75,8 @@ def test_linear_rows_in_place_residual(dev, L):
     x, w, b = torch.randn(m, k, generator=g), torch.randn(k, k, generator=g) / 16, torch.randn(k, generator=g)
     e = torch.randn(m, k, generator=g)
     ref = e.double() + x.double() @ w.double().t() + b.double()
-    ed = e.to(dev)
-    L.check(L.lib().difusco_linear_rows(_p(x.to(dev)), _p(w.to(dev)), _p(b.to(dev)), _p(ed), _p(ed), m, k, k, k, _stream()))
+    ed, xd, wd, bd = e.to(dev), x.to(dev), w.to(dev), b.to(dev)
+    L.check(L.lib().difusco_linear_rows(_p(xd), _p(wd), _p(bd), _p(ed), _p(ed), m, k, k, k, _stream()))
     torch.cuda.synchronize()
     assert (ed.cpu().double() - ref).abs().max().item() < 5e-5
 
