@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 H, LAYERS = 256, 12
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0              # HBM3E spec
 
 
@@ -68,6 +69,9 @@ def main():
     ap.add_argument("--graphs-per-gpu", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (0 = skip cpu_baseline)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-library HIP-event brackets")
+    ap.add_argument("--precision", default="bf16x6", choices=["fp32", "bf16x3", "bf16x6"],
+                    help="arithmetic of the E-row linears: exact fp32 MFMA, or fp32 split into 2/3 bf16 planes "
+                         "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,9 +100,9 @@ def main():
     # frozen weights: rank 0 creates, RCCL broadcast of the packed blob over xGMI
     params = random_state_dict(H, LAYERS, 2, seed=20240926) if rank == 0 or world == 1 else None
     if world > 1:
-        engine = engine_from_broadcast(params, device, src=0)
+        engine = engine_from_broadcast(params, device, src=0, precision=args.precision)
     else:
-        engine = DenoiseEngine(params, device=device)
+        engine = DenoiseEngine(params, device=device, precision=args.precision)
     margs = dict(diffusion_type="categorical", diffusion_schedule="linear", diffusion_steps=1000,
                  inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn,
                  n_layers=LAYERS, hidden_dim=H)
@@ -159,19 +163,33 @@ def main():
                                    f"{args.graphs_per_gpu} graphs per GPU (global batch {G_total}), H={H}, {LAYERS} layers",
                        "graphs_per_gpu": args.graphs_per_gpu, "global_batch": G_total, "nodes": args.nodes,
                        "knn": args.knn, "edges_per_graph": args.nodes * args.knn, "gn_stats": GN_STATS_MODE,
-                       "rng": "on-device philox", "weights_seed": 20240926},
+                       "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision},
         }
         if prof is not None and prof["launches"][0] > 0:
             n_lin = prof["launches"][0]
             avg_s = prof["ms"][0] / n_lin * 1e-3
-            flops = 2.0 * E_local * H * H                       # one E-row linear: [E,H] x [H,H]^T
-            achieved = flops / avg_s / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                               "kernel": "linear_rows_kernel<256,256,16> (E-row linear, fp32 MFMA)",
-                               "avg_launch_ms": avg_s * 1e3, "launches": n_lin,
-                               "algorithmic_flops_per_launch": flops,
-                               "algorithmic_bytes_per_launch": 2.0 * E_local * H * 4}
+            # one E-row linear [E,H] x [H,H]^T.  Algorithmic bytes: read X + write Y (+ read residual for the
+            # per_layer_out linear = every second launch) -> 2.5 passes of E*H*4 on average.
+            flops = 2.0 * E_local * H * H
+            n_prod = {"fp32": 1, "bf16x3": 3, "bf16x6": 6}[args.precision]
+            mfma_peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            mfma_tf = flops * n_prod / avg_s / 1e12          # matrix-core work actually issued
+            bytes_alg = 2.5 * E_local * H * 4
+            hbm_gbs = bytes_alg / avg_s / 1e9
+            kname = ("linear_rows_kernel<256,256,16> (E-row linear, exact fp32 MFMA)" if args.precision == "fp32" else
+                     f"linear_rows_split_kernel<256,256,{2 if args.precision == 'bf16x3' else 3}> "
+                     f"(E-row linear, fp32 split into bf16 planes, {n_prod} MFMA products)")
+            if mfma_tf / mfma_peak >= hbm_gbs / PEAK_HBM_GBS:
+                out["roofline"] = {"bound": "mfma", "achieved": mfma_tf, "peak": mfma_peak, "unit": "TFLOP/s",
+                                   "frac": mfma_tf / mfma_peak, "traffic": None}
+            else:
+                out["roofline"] = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": None}
+            out["roofline"].update({"kernel": kname, "avg_launch_ms": avg_s * 1e3, "launches": n_lin,
+                                    "algorithmic_flops_per_launch": flops, "mfma_products": n_prod,
+                                    "algorithmic_bytes_per_launch": bytes_alg,
+                                    "mfma_TFLOPs_issued": mfma_tf, "mfma_peak_TFLOPs": mfma_peak,
+                                    "hbm_GBs_algorithmic": hbm_gbs})
             n_g = max(prof["launches"][2], 1)
             g_s = prof["ms"][2] / n_g * 1e-3
             gate_bytes = 2.0 * E_local * H * 4                  # read C e, write act (node tables are L2/MALL traffic)

@@ -5,21 +5,24 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
+PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
+PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
 
 # indices into difusco_weights_layout() (mirrors the enums of include/difusco_hip.h)
 W_GLOBAL = ["node_embed.weight", "node_embed.bias", "edge_embed.weight", "edge_embed.bias",
             "time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias",
             "out.0.weight", "out.0.bias", "out.2.weight", "out.2.bias",
-            "@time_freqs", "@dimt_pos", "@dimt_scalar"]
+            "@time_freqs", "@dimt_pos", "@dimt_scalar", "@planes:edge_embed.weight"]
 W_LAYER = ["@node4.weight", "@node4.bias", "layers.{l}.C.weight", "layers.{l}.C.bias",
            "layers.{l}.norm_h.weight", "layers.{l}.norm_h.bias", "layers.{l}.norm_e.weight", "layers.{l}.norm_e.bias",
            "time_embed_layers.{l}.1.weight", "time_embed_layers.{l}.1.bias",
            "per_layer_out.{l}.0.weight", "per_layer_out.{l}.0.bias",
-           "per_layer_out.{l}.2.weight", "per_layer_out.{l}.2.bias"]
+           "per_layer_out.{l}.2.weight", "per_layer_out.{l}.2.bias",
+           "@planes:layers.{l}.C.weight", "@planes:per_layer_out.{l}.2.weight"]
 
 
 class StepArgs(ctypes.Structure):
@@ -39,6 +42,7 @@ class StepArgs(ctypes.Structure):
         ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
         ("xt_out", ctypes.c_void_p), ("pred_out", ctypes.c_void_p), ("prob_out", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("stream", ctypes.c_void_p),
+        ("precision", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -68,6 +72,7 @@ def lib():
     L.difusco_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.difusco_denoise_step.argtypes = [ctypes.POINTER(StepArgs)]
     L.difusco_linear_rows.argtypes = [f32p, f32p, f32p, f32p, f32p, i64, i32, i32, i64, vp]
+    L.difusco_linear_rows_split.argtypes = [f32p, vp, i32, f32p, f32p, f32p, i64, i32, i32, i64, vp]
     L.difusco_edge_gate_aggregate.argtypes = [i32, i32, vp, vp, f32p, f32p, f32p] + [f32p] * 7 + [i32, vp]
     L.difusco_categorical_posterior.argtypes = [f32p, f32p, ctypes.POINTER(ctypes.c_float), i32, f32p,
                                                 ctypes.c_uint64, ctypes.c_uint64, f32p, f32p, i64, vp]

@@ -55,6 +55,7 @@ Layout make_layout(int H, int L, int C) {
   push(H); push(H);                       // out.0 (GroupNorm affine)
   push((int64_t)C * H); push(C);          // out.2 (1x1 conv)
   push(T2); push(T2); push(H);            // freqs, dimt_pos, dimt_scalar
+  push((int64_t)3 * H * H / 2);           // edge_embed bf16 planes (3 planes of H*H bf16)
   const int64_t layer0 = cur;
   for (int l = 0; l < L; ++l) {
     push((int64_t)4 * H * H); push((int64_t)4 * H);  // node4 = U|V|A|B
@@ -63,6 +64,7 @@ Layout make_layout(int H, int L, int C) {
     push((int64_t)H * T2); push(H);                   // time layer
     push(H); push(H);                                 // per_layer_out LN
     push((int64_t)H * H); push(H);                    // per_layer_out linear
+    push((int64_t)3 * H * H / 2); push((int64_t)3 * H * H / 2);  // bf16 planes of C and per_layer_out
     if (l == 0) lo.layer_stride = cur - layer0;
   }
   lo.total = cur;
@@ -220,6 +222,16 @@ int difusco_denoise_step(const difusco_step_args* a) {
   auto G = [&](int id) { return W + lo.off[id]; };
   auto LW = [&](int l, int id) { return W + lo.off[DIFUSCO_W_GLOBAL_COUNT + l * DIFUSCO_WL_COUNT + id]; };
   hipStream_t st = (hipStream_t)a->stream;
+  if (a->precision < DIFUSCO_PREC_FP32 || a->precision > DIFUSCO_PREC_BF16X6)
+    return fail(DIFUSCO_EINVAL, "unknown precision %d", a->precision);
+  const int n_planes = a->precision == DIFUSCO_PREC_BF16X3 ? 2 : 3;
+  // E-row linear: exact fp32 MFMA or bf16 split planes, same contract
+  auto edge_linear = [&](const float* x, const float* w, const float* planes, const float* b, const float* res,
+                         float* y) -> hipError_t {
+    if (a->precision == DIFUSCO_PREC_FP32) return linear_rows(x, w, b, res, y, E, H, H, H, st);
+    return linear_rows_split(x, reinterpret_cast<const unsigned short*>(planes), (long long)H * H, n_planes, b, res, y,
+                             E, H, H, H, st);
+  };
 
   // PROF(category, call): HIP_TRY(call), bracketed by a pair of HIP events on `st` when profiling is on
 #define PROF(cat, call)      \
@@ -248,8 +260,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
       PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, ws.table, E, H, ws.e, st))
     } else {
       PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
-      PROF(PROF_LINEAR_EDGE, linear_rows(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.e, E,
-                                         H, H, H, st))
+      PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_PLANES),
+                                         G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.e))
     }
   } else {
     PROF(PROF_EMBED, launch_scalar_embed(a->xt, nullptr, G(DIFUSCO_W_DIMT_SCALAR), N, H, ws.node4, st))
@@ -262,13 +274,15 @@ int difusco_denoise_step(const difusco_step_args* a) {
   for (int l = 0; l < L; ++l) {
     PROF(PROF_LINEAR_NODE, linear_rows(ws.h, LW(l, DIFUSCO_WL_NODE4_W), LW(l, DIFUSCO_WL_NODE4_B), nullptr, ws.node4, N,
                                        H, 4 * H, 4 * H, st))
-    PROF(PROF_LINEAR_EDGE, linear_rows(ws.e, LW(l, DIFUSCO_WL_C_W), LW(l, DIFUSCO_WL_C_B), nullptr, ws.tmp, E, H, H, H, st))
+    PROF(PROF_LINEAR_EDGE, edge_linear(ws.e, LW(l, DIFUSCO_WL_C_W), LW(l, DIFUSCO_WL_C_PLANES), LW(l, DIFUSCO_WL_C_B),
+                                       nullptr, ws.tmp))
     PROF(PROF_GATE, launch_edge_gate_aggregate(H, (int)N, a->rowptr, a->col, ws.node4, ws.tmp, ws.h,
                                                LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
                                                LW(l, DIFUSCO_WL_NORM_E_W), LW(l, DIFUSCO_WL_NORM_E_B),
                                                LW(l, DIFUSCO_WL_OUT_LN_W), LW(l, DIFUSCO_WL_OUT_LN_B),
                                                ws.tbias + (size_t)l * H, tsp ? 1 : 0, st))
-    PROF(PROF_LINEAR_EDGE, linear_rows(ws.tmp, LW(l, DIFUSCO_WL_OUT_W), LW(l, DIFUSCO_WL_OUT_B), ws.e, ws.e, E, H, H, H, st))
+    PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, LW(l, DIFUSCO_WL_OUT_W), LW(l, DIFUSCO_WL_OUT_PLANES),
+                                       LW(l, DIFUSCO_WL_OUT_B), ws.e, ws.e))
   }
 
   // head + posterior (gnn_encoder.py:400-401 / :412-413, pl_tsp_model.py:133-137, pl_meta_model.py:102-175)
@@ -286,6 +300,19 @@ int difusco_linear_rows(const float* x, const float* w, const float* bias, const
   if (!(k == 32 || k == 64 || k == 128 || k == 256) || n_out % 32 != 0 || n_out <= 0 || ldy < n_out)
     return fail(DIFUSCO_EINVAL, "k must be 32/64/128/256, n_out a positive multiple of 32, ldy >= n_out");
   HIP_TRY(difusco::linear_rows(x, w, bias, residual, y, m, k, n_out, ldy, (hipStream_t)stream));
+  return DIFUSCO_OK;
+}
+
+int difusco_linear_rows_split(const float* x, const void* planes, int precision, const float* bias,
+                              const float* residual, float* y, int64_t m, int k, int n_out, int64_t ldy, void* stream) {
+  if (!x || !planes || !y) return fail(DIFUSCO_EINVAL, "null pointer");
+  if (precision != DIFUSCO_PREC_BF16X3 && precision != DIFUSCO_PREC_BF16X6)
+    return fail(DIFUSCO_EINVAL, "precision must be BF16X3 or BF16X6");
+  if (k != n_out || !(k == 64 || k == 128 || k == 256) || ldy < n_out)
+    return fail(DIFUSCO_EINVAL, "split path needs k == n_out in {64,128,256}, ldy >= n_out");
+  HIP_TRY(difusco::linear_rows_split(x, reinterpret_cast<const unsigned short*>(planes), (long long)n_out * k,
+                                     precision == DIFUSCO_PREC_BF16X3 ? 2 : 3, bias, residual, y, m, k, n_out, ldy,
+                                     (hipStream_t)stream));
   return DIFUSCO_OK;
 }
 

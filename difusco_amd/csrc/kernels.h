@@ -7,6 +7,10 @@ namespace difusco {
 hipError_t linear_rows(const float* x, const float* w, const float* bias, const float* residual, float* y,
                        long long m, int k, int n_out, long long ldy, hipStream_t stream);
 
+hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int n_planes,
+                             const float* bias, const float* residual, float* y, long long m, int k, int n_out,
+                             long long ldy, hipStream_t stream);
+
 hipError_t launch_time_bias(float t, int H, int n_layers, const float* freqs, const float* w0, const float* b0,
                             const float* w2, const float* b2, const float* wl_base, long long layer_stride,
                             long long wl_w_off, long long wl_b_off, float* tbias, hipStream_t stream);

@@ -1,0 +1,192 @@
+// Split-precision row-linear on the gfx950 bf16 matrix cores:  Y = X * W^T + b (+ residual), fp32 in and
+// out, each fp32 operand decomposed into NS bf16 planes (x = hi + mid (+ lo), round-to-nearest-even):
+//   NS = 2 -> 3 MFMA products  (hi*hi, hi*mid, mid*hi)                       ~2^-17 relative per product
+//   NS = 3 -> 6 MFMA products  (+ hi*lo, lo*hi, mid*mid): 8+8+8 = 24 mantissa bits, i.e. the full fp32
+//             significand of both operands; dropped terms are <= 2^-24 relative -> fp32-class accuracy.
+// Products of bf16 pairs are exact in the fp32 accumulator, so the only rounding is the fp32 accumulation
+// itself.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md),
+// so 6 products cost 6/16 of the exact-fp32 MFMA path and the E-row linears of the DIFUSCO layer
+// (difusco/models/gnn_encoder.py:104 `C`, :344 `per_layer_out[2]`, :395 `edge_embed`) become HBM-bound.
+//
+// Same orientation as linear.hip (transposed: A = 32 weight rows, B = 32 data rows; a lane owns 4
+// consecutive output features of one data row per accumulator quad).  Weights arrive PRE-SPLIT from the
+// host (weights.py) as planes laid out [K/16 slabs][n_out rows][16 k] bf16, so a slab is one linear
+// stream; X is split on the fly while it is staged into LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace difusco {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+// (a, b) -> packed bf16 pair (RNE) and the fp32 remainders
+__device__ __forceinline__ unsigned split_pair(float& a, float& b) {
+  v2f f = {a, b};
+  v2bf h = __builtin_convertvector(f, v2bf);
+  a -= (float)h[0];
+  b -= (float)h[1];
+  return __builtin_bit_cast(unsigned, h);
+}
+
+template <int K, int FB, int NS>
+__global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* __restrict__ X,
+                                                                    const unsigned short* __restrict__ Wp,
+                                                                    long long plane_stride,  // elements between planes
+                                                                    int n_out_total,
+                                                                    const float* __restrict__ bias,
+                                                                    const float* residual, float* Y, long long M,
+                                                                    long long ldy) {
+  constexpr int RB = 128, NB = FB / 32, BK = 16;
+  constexpr int RS = 24;                 // LDS row stride in bf16 elements (32 B data + 16 B pad = 48 B)
+  constexpr int WV = (FB * 2 + 255) / 256;  // 16-byte chunks per thread per weight plane per slab
+  static_assert(K % BK == 0, "K must be a multiple of 16");
+  static_assert(NS == 2 || NS == 3, "2 or 3 planes");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem_s[];
+  unsigned short* Xs = smem_s;                         // [NS][RB][RS]
+  unsigned short* Ws = smem_s + NS * RB * RS;          // [NS][FB][RS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const long long r0 = (long long)blockIdx.x * RB;
+  const int f0 = blockIdx.y * FB;
+
+  v16f acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+
+  v4f xr[2];
+  v4u wr[NS][WV];
+
+#define DIFUSCO_LOAD(KT)                                                                              \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
+      const int idx = tid + 256 * i;                                                                  \
+      const int row = idx >> 2, c4 = idx & 3;                                                         \
+      long long gr = r0 + row;                                                                        \
+      gr = gr < M ? gr : M - 1;                                                                       \
+      xr[i] = *reinterpret_cast<const v4f*>(X + gr * K + (KT) + c4 * 4);                              \
+    }                                                                                                 \
+    const unsigned short* wslab = Wp + ((long long)((KT) / BK) * n_out_total + f0) * BK;              \
+    _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                  \
+      _Pragma("unroll") for (int i = 0; i < WV; ++i) {                                                \
+        int c = tid + 256 * i;                                                                        \
+        if (FB * 2 % 256 != 0) c = c < FB * 2 ? c : FB * 2 - 1;                                       \
+        wr[p][i] = *reinterpret_cast<const v4u*>(wslab + p * plane_stride + (long long)c * 8);        \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+#define DIFUSCO_STORE()                                                                               \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
+      const int idx = tid + 256 * i;                                                                  \
+      const int row = idx >> 2, c4 = idx & 3;                                                         \
+      float a = xr[i][0], b = xr[i][1], c = xr[i][2], d = xr[i][3];                                   \
+      _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                \
+        v2u pk;                                                                                       \
+        pk[0] = split_pair(a, b);                                                                     \
+        pk[1] = split_pair(c, d);                                                                     \
+        *reinterpret_cast<v2u*>(Xs + (p * RB + row) * RS + c4 * 4) = pk;                              \
+      }                                                                                               \
+    }                                                                                                 \
+    _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                  \
+      _Pragma("unroll") for (int i = 0; i < WV; ++i) {                                                \
+        int c = tid + 256 * i;                                                                        \
+        if (FB * 2 % 256 != 0) c = c < FB * 2 ? c : FB * 2 - 1;                                       \
+        *reinterpret_cast<v4u*>(Ws + (p * FB + (c >> 1)) * RS + (c & 1) * 8) = wr[p][i];             \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+
+  DIFUSCO_LOAD(0)
+  DIFUSCO_STORE()
+  __syncthreads();
+
+  const unsigned short* xrow = Xs + (wave * 32 + l31) * RS + hh * 8;
+  const unsigned short* wrow = Ws + l31 * RS + hh * 8;
+
+  for (int kt = 0; kt < K; kt += BK) {
+    const int kn = (kt + BK) < K ? kt + BK : kt;
+    DIFUSCO_LOAD(kn)
+    v8bf xb[NS];
+#pragma unroll
+    for (int p = 0; p < NS; ++p) xb[p] = *reinterpret_cast<const v8bf*>(xrow + p * RB * RS);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      v8bf wa[NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) wa[p] = *reinterpret_cast<const v8bf*>(wrow + (p * FB + nb * 32) * RS);
+      // smallest terms first
+      if constexpr (NS == 3) {
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[2], xb[0], acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[2], acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb[1], acc[nb], 0, 0, 0);
+      }
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb[0], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[1], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[0], acc[nb], 0, 0, 0);
+    }
+    __syncthreads();
+    DIFUSCO_STORE()
+    __syncthreads();
+  }
+#undef DIFUSCO_LOAD
+#undef DIFUSCO_STORE
+
+  const long long row = r0 + wave * 32 + l31;
+  if (row < M) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f = f0 + nb * 32 + 8 * g + 4 * hh;
+        v4f v = {acc[nb][4 * g + 0], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
+        if (bias != nullptr) v += *reinterpret_cast<const v4f*>(bias + f);
+        if (residual != nullptr) v += *reinterpret_cast<const v4f*>(residual + row * ldy + f);
+        *reinterpret_cast<v4f*>(Y + row * ldy + f) = v;
+      }
+    }
+  }
+}
+
+template <int K, int FB, int NS>
+static hipError_t launch_split(const float* x, const unsigned short* wp, long long plane_stride, const float* bias,
+                               const float* residual, float* y, long long m, int n_out, long long ldy, hipStream_t stream) {
+  constexpr size_t lds = (size_t)NS * (128 + FB) * 24 * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_split_kernel<K, FB, NS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((m + 127) / 128), (unsigned)(n_out / FB));
+  hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
+                     bias, residual, y, m, ldy);
+  return hipGetLastError();
+}
+
+// wp: NS..3 planes, plane p at wp + p*plane_stride, each [K/16][n_out][16] bf16.  n_planes = 2 or 3.
+hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int n_planes,
+                             const float* bias, const float* residual, float* y, long long m, int k, int n_out,
+                             long long ldy, hipStream_t stream) {
+  if (m <= 0) return hipSuccess;
+  if (n_planes != 2 && n_planes != 3) return hipErrorInvalidValue;
+#define DIFUSCO_SPLIT_CASE(KK, FBB)                                                                              \
+  if (k == KK && n_out % FBB == 0) {                                                                             \
+    return n_planes == 2 ? launch_split<KK, FBB, 2>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream) \
+                         : launch_split<KK, FBB, 3>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream); \
+  }
+  DIFUSCO_SPLIT_CASE(256, 256)
+  DIFUSCO_SPLIT_CASE(128, 128)
+  DIFUSCO_SPLIT_CASE(64, 64)
+#undef DIFUSCO_SPLIT_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace difusco

@@ -57,7 +57,8 @@ class BlobEngineConfig(dict):
         }
 
 
-def engine_from_broadcast(state_dict: Optional[dict], device, src: int = 0, group=None):
+def engine_from_broadcast(state_dict: Optional[dict], device, src: int = 0, group=None, precision: str = "bf16x6"):
     from .engine import DenoiseEngine
     (hidden, n_layers, out_channels), blob = broadcast_weights(state_dict, device, src, group)
-    return DenoiseEngine(BlobEngineConfig.make(hidden, n_layers, out_channels), device=device, blob=blob)
+    return DenoiseEngine(BlobEngineConfig.make(hidden, n_layers, out_channels), device=device, blob=blob,
+                         precision=precision)

@@ -16,7 +16,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class DenoiseEngine:
-    def __init__(self, state_dict, device="cuda:0", blob: Optional[torch.Tensor] = None):
+    def __init__(self, state_dict, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "bf16x6"):
         """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
         ``blob``: an already packed blob (e.g. received by RCCL broadcast) instead of packing here."""
         self.device = torch.device(device)
@@ -27,6 +27,9 @@ class DenoiseEngine:
         if blob is None:
             blob = pack_state_dict(state_dict)
         self.blob = blob.to(self.device, dtype=torch.float32).contiguous()
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
+        self.precision = precision
         self._ws = None
         self.calls = 0
 
@@ -87,6 +90,7 @@ class DenoiseEngine:
         a.xt_out, a.pred_out, a.prob_out = _ptr(xt_out), _ptr(pred), _ptr(prob)
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
         a.stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        a.precision = _lib.PRECISIONS[self.precision]
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
         self.calls += 1

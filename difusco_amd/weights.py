@@ -37,6 +37,18 @@ def constant_tables(hidden: int):
     return {"@time_freqs": freqs, "@dimt_pos": dim_t(half), "@dimt_scalar": dim_t(hidden)}
 
 
+def split_planes(w: torch.Tensor) -> torch.Tensor:
+    """[n_out, k] fp32 -> the three bf16 planes hi | mid | lo (RNE), each laid out [k/16][n_out][16],
+    returned as a flat fp32-typed view (3*n_out*k/2 floats) ready to be copied into the blob."""
+    n_out, k = w.shape
+    planes, rest = [], w.clone()
+    for _ in range(3):
+        p = rest.to(torch.bfloat16)
+        rest = rest - p.float()
+        planes.append(p.reshape(n_out, k // 16, 16).permute(1, 0, 2).contiguous().reshape(-1))
+    return torch.cat(planes).view(torch.int16).view(torch.float32)
+
+
 def pack_state_dict(state) -> torch.Tensor:
     """-> 1-D fp32 CPU tensor laid out per ``difusco_weights_layout``."""
     state = {k: (v.detach().float().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v)).float())
@@ -50,8 +62,13 @@ def pack_state_dict(state) -> torch.Tensor:
         flat = tensor.reshape(-1)
         blob[offsets[idx]: offsets[idx] + flat.numel()] = flat
 
+    def fetch(name):
+        if name.startswith("@planes:"):
+            return split_planes(state[name[len("@planes:"):]].reshape(hidden, hidden))
+        return consts[name] if name.startswith("@") else state[name]
+
     for i, name in enumerate(_lib.W_GLOBAL):
-        put(i, consts[name] if name.startswith("@") else state[name])
+        put(i, fetch(name))
     for l in range(n_layers):
         base = len(_lib.W_GLOBAL) + l * len(_lib.W_LAYER)
         for i, name in enumerate(_lib.W_LAYER):
@@ -60,6 +77,6 @@ def pack_state_dict(state) -> torch.Tensor:
             elif name == "@node4.bias":
                 t = torch.cat([state[f"layers.{l}.{m}.bias"] for m in "UVAB"], dim=0)
             else:
-                t = state[name.format(l=l)]
+                t = fetch(name.format(l=l))
             put(base + i, t)
     return blob

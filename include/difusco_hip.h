@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 1
+#define DIFUSCO_ABI_VERSION 2
 
 enum {
   DIFUSCO_OK = 0,
@@ -36,6 +36,11 @@ enum {
 
 enum { DIFUSCO_TASK_TSP = 0, DIFUSCO_TASK_MIS = 1 };            /* edge features | node features only */
 enum { DIFUSCO_CATEGORICAL = 0, DIFUSCO_GAUSSIAN = 1 };
+enum {
+  DIFUSCO_PREC_FP32 = 0,   /* E-row linears on v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fma chain) */
+  DIFUSCO_PREC_BF16X3 = 1, /* 2 bf16 planes, 3 products: ~2^-17 relative per product                    */
+  DIFUSCO_PREC_BF16X6 = 2  /* 3 bf16 planes, 6 products: all 24 significand bits, fp32-class accuracy    */
+};
 enum {
   DIFUSCO_RAND_NONE = 0,     /* no draw: categorical final step (target_t == 0) or DDIM */
   DIFUSCO_RAND_INJECTED = 1, /* caller supplies uniforms (categorical) / normals (gaussian DDPM) */
@@ -58,6 +63,7 @@ enum {
   DIFUSCO_W_TIME_FREQS,  /* [H/2]  exp(-ln(1e4) k/(H/2))                      */
   DIFUSCO_W_DIMT_POS,    /* [H/2]  1e4^(2(k/2)/(H/2))  PositionEmbeddingSine   */
   DIFUSCO_W_DIMT_SCALAR, /* [H]    1e4^(2(k/2)/H)      ScalarEmbeddingSine(1D) */
+  DIFUSCO_W_EDGE_EMBED_PLANES, /* bf16 split planes of edge_embed.weight, see below */
   DIFUSCO_W_GLOBAL_COUNT
 };
 enum {                       /* per layer l, index = GLOBAL_COUNT + l*LAYER_COUNT + id */
@@ -68,8 +74,14 @@ enum {                       /* per layer l, index = GLOBAL_COUNT + l*LAYER_COUN
   DIFUSCO_WL_TIME_W, DIFUSCO_WL_TIME_B,      /* time_embed_layers[l].1 : [H,H/2],[H] */
   DIFUSCO_WL_OUT_LN_W, DIFUSCO_WL_OUT_LN_B,  /* per_layer_out[l].0                   */
   DIFUSCO_WL_OUT_W, DIFUSCO_WL_OUT_B,        /* per_layer_out[l].2 : [H,H],[H]       */
+  DIFUSCO_WL_C_PLANES, DIFUSCO_WL_OUT_PLANES, /* bf16 split planes of C / per_layer_out[l].2 */
   DIFUSCO_WL_COUNT
 };
+/* "*_PLANES" entries: the [H,H] weight w decomposed on the host into three bf16 planes
+ *   hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid)      (round to nearest even)
+ * stored back to back (plane stride H*H bf16 elements), each plane laid out [H/16 slabs][H rows][16 k]
+ * (slab s, row f, j  <->  w[f][16 s + j]).  3*H*H bf16 = 1.5*H*H floats of blob space per matrix.
+ * They feed the split-precision MFMA path selected by difusco_step_args.precision. */
 /* Fills offsets[0 .. GLOBAL_COUNT + n_layers*WL_COUNT) (floats from blob start) and *total_floats.
  * Returns the number of entries, or a negative error. */
 int difusco_weights_layout(int hidden, int n_layers, int out_channels,
@@ -135,6 +147,8 @@ typedef struct difusco_step_args {
   void* workspace;        /* device, >= difusco_workspace_bytes(...) */
   size_t workspace_bytes;
   void* stream;           /* hipStream_t */
+  int32_t precision;      /* DIFUSCO_PREC_*: arithmetic of the E-row linears (node rows stay exact fp32) */
+  int32_t reserved0;
 } difusco_step_args;
 
 size_t difusco_workspace_bytes(int hidden, int n_layers, int n_nodes, int n_edges, int n_segments);
@@ -148,6 +162,12 @@ int difusco_denoise_step(const difusco_step_args* args);
  * k in {32,64,128,256}; n_out multiple of 32.  fp32 MFMA (v_mfma_f32_32x32x2_f32). */
 int difusco_linear_rows(const float* x, const float* w, const float* bias, const float* residual,
                         float* y, int64_t m, int k, int n_out, int64_t ldy, void* stream);
+/* Same contract on the split-precision path: `planes` = 3 bf16 planes of W[n_out,k] in the *_PLANES
+ * layout above (plane stride n_out*k elements); precision = DIFUSCO_PREC_BF16X3 | DIFUSCO_PREC_BF16X6.
+ * k == n_out in {64,128,256}. */
+int difusco_linear_rows_split(const float* x, const void* planes, int precision, const float* bias,
+                              const float* residual, float* y, int64_t m, int k, int n_out, int64_t ldy,
+                              void* stream);
 
 /* One gated-GCN message-passing pass (gnn_encoder.py:110-135 + :445-448 + per_layer_out LN/SiLU):
  *   e' = Ah[j]+Bh[i]+Ce ; h[i] += ReLU(LN_h(Uh[i] + sum_j sigmoid(e')*Vh[j])) (+tbias, MIS)

@@ -81,6 +81,33 @@ def test_linear_rows_in_place_residual(dev, L):
     assert (ed.cpu().double() - ref).abs().max().item() < 5e-5
 
 
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16x6", 6e-7)])
+@pytest.mark.parametrize("m,k", [(1, 256), (127, 256), (4099, 256), (300, 128), (77, 64)])
+def test_linear_rows_split(dev, L, prec, tol, m, k):
+    """Split-precision bf16 MFMA path (3 or 6 products) against fp64; error relative to max|Y|."""
+    from difusco_amd import weights
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(k, k, generator=g) / np.sqrt(k) + torch.arange(k).float()[:, None] * 1e-3   # asymmetric
+    b = torch.randn(k, generator=g)
+    r = torch.randn(m, k, generator=g)
+    ref = x.double() @ w.double().t() + b.double() + r.double()
+    planes = weights.split_planes(w).to(dev)
+    xd, bd, rd = x.to(dev), b.to(dev), r.to(dev)
+    y = torch.full((m, k), float("nan"), device=dev)
+    L.check(L.lib().difusco_linear_rows_split(_p(xd), _p(planes), L.PRECISIONS[prec], _p(bd), _p(rd), _p(y), m, k, k, k, _stream()))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"{prec} m={m} k={k}: rel err {err:.2e}")
+    assert err < tol, err
+    # in place residual (Y == residual), no bias
+    ed = r.to(dev)
+    L.check(L.lib().difusco_linear_rows_split(_p(xd), _p(planes), L.PRECISIONS[prec], None, _p(ed), _p(ed), m, k, k, k, _stream()))
+    torch.cuda.synchronize()
+    ref2 = x.double() @ w.double().t() + r.double()
+    assert (ed.cpu().double() - ref2).abs().max().item() / ref2.abs().max().item() < tol
+
+
 def test_linear_rows_rejects_bad_shapes(L, dev):
     x = torch.zeros(4, 100, device=dev)
     assert L.lib().difusco_linear_rows(_p(x), _p(x), None, None, _p(x), 4, 100, 64, 64, _stream()) == -1
@@ -302,8 +329,9 @@ def test_golden_mis(dev, golden_dir):
         assert np.abs(out.cpu().numpy() - z[f"gau{i}_out"]).max() < TOL
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3"])
 @pytest.mark.parametrize("H,Lyr,N,K,G", [(256, 3, 60, 10, 2), (256, 12, 100, 20, 1), (128, 2, 33, 5, 3)])
-def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G):
+def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
     """H=256 / 12 layers (the production width) against the oracle on seeded synthetic inputs,
     teacher-forced, plus shuffled (non row-sorted) edge order through the perm path."""
     from difusco_amd import TSPModel
@@ -315,14 +343,14 @@ def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G):
     xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
     u = torch.rand(ei.shape[1], generator=g)
     tab = O.CategoricalTables()
-    m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev)
+    m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev, precision=prec)
     for (t, tt) in [(1000, 969), (57, 31), (1, 0)]:
         ref_out, ref_logits, ref_prob = O.tsp_categorical_denoise_step(p, tab, pts, xt, t, ei, tt, uniform=u, return_aux=True)
         out, logits, prob = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev),
                                                        target_t=np.array([tt]), uniform=u, return_aux=True)
         e_log = (logits.cpu() - ref_logits).abs().max().item()
         e_prob = (prob.cpu() - ref_prob.reshape(-1)).abs().max().item()
-        print(f"H={H} L={Lyr} t={t}: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
+        print(f"{prec} H={H} L={Lyr} t={t}: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
         assert e_log < TOL and e_prob < TOL
         if tt > 0:
             safe = (u - ref_prob.reshape(-1)).abs() > 1e-4
@@ -340,7 +368,8 @@ def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G):
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 
-def test_oracle_tsp_gaussian_full_width(dev):
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3"])
+def test_oracle_tsp_gaussian_full_width(dev, prec):
     from difusco_amd import TSPModel
     H, Lyr, N, K = 256, 4, 80, 12
     p = O.init_params(H, Lyr, 1, seed=77)
@@ -351,13 +380,31 @@ def test_oracle_tsp_gaussian_full_width(dev):
     z = torch.randn(ei.shape[1], generator=g)
     tab = O.GaussianTables()
     for trick, steps in [("ddim", [(1000, 969), (1, 0)]), (None, [(700, 699)])]:
-        m = TSPModel(_args("gaussian", K, trick=trick, H=H, L=Lyr), p, device=dev)
+        m = TSPModel(_args("gaussian", K, trick=trick, H=H, L=Lyr), p, device=dev, precision=prec)
         for (t, tt) in steps:
             ref_out, ref_pred = O.tsp_gaussian_denoise_step(p, tab, pts, xt, t, ei, tt, inference_trick=trick, noise=z, return_aux=True)
             out, pred = m.gaussian_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev), target_t=np.array([tt]),
                                                 noise=z, return_aux=True)
-            assert (pred.cpu() - ref_pred).abs().max().item() < TOL
+            e_pred = (pred.cpu() - ref_pred).abs().max().item()
+            print(f"{prec} gaussian t={t}: eps L_inf {e_pred:.3e}")
+            assert e_pred < TOL
             assert (out.cpu() - ref_out).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+def test_golden_tsp_sparse_precisions(dev, golden_dir, prec):
+    """The reference-generated fixture through both the exact-fp32 and the default split path."""
+    from difusco_amd import TSPModel
+    z = np.load(os.path.join(golden_dir, "tsp_sparse_h64_l2_g3.npz"))
+    cat, _ = _golden_weights(golden_dir)
+    pts, ei = torch.from_numpy(z["points"]).to(dev), torch.from_numpy(z["edge_index"]).to(dev)
+    m = TSPModel(_args("categorical"), cat, device=dev, precision=prec)
+    for i in range(4):
+        t, tt = z[f"cat{i}_t"]
+        u = torch.from_numpy(z[f"cat{i}_uniform"]).reshape(-1) if f"cat{i}_uniform" in z.files else None
+        out, logits, prob = m.categorical_denoise_step(pts, torch.from_numpy(z[f"cat{i}_xt"]).to(dev), np.array([t]), dev,
+                                                       ei, target_t=np.array([tt]), uniform=u, return_aux=True)
+        print(f"{prec} golden step {i}: logits L_inf {_check_cat(z, i, out, logits, prob):.3e}")
 
 
 def test_oracle_mis_full_width(dev):

@@ -182,3 +182,46 @@ def test_engine_refuses_cpu_device():
     from difusco_amd.engine import DenoiseEngine
     with pytest.raises(_lib.DifuscoHipError):
         DenoiseEngine(O.init_params(64, 1, 2, 0), device="cpu")
+
+
+def _emulated_split_gemm(x, w, n_planes):
+    """CPU emulation of linear_rows_split_kernel's arithmetic: operands decomposed into bf16 planes
+    (RNE), every bf16 x bf16 product exact, accumulation in fp32 (here fp64 of exactly representable
+    products - an upper bound on the kernel's accuracy, the kernel adds fp32 accumulation rounding)."""
+    def planes(t):
+        out, rest = [], t.clone()
+        for _ in range(n_planes):
+            p = rest.to(torch.bfloat16).float()
+            rest = rest - p
+            out.append(p.double())
+        return out
+    xp, wp = planes(x), planes(w)
+    pairs = [(0, 0), (0, 1), (1, 0)] if n_planes == 2 else [(0, 0), (0, 1), (1, 0), (0, 2), (2, 0), (1, 1)]
+    return sum(xp[a] @ wp[b].t() for a, b in pairs)
+
+
+def test_split_precision_error_model():
+    """bf16x3 (2 planes / 3 products) vs bf16x6 (3 planes / 6 products) against fp64: documents why
+    bf16x6 is 'fp32-class' (dropped terms <= 2^-24) while bf16x3 sits near 2^-17 per product."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(512, 256, generator=g)
+    w = (torch.rand(256, 256, generator=g) * 2 - 1) / 16
+    ref = x.double() @ w.double().t()
+    scale = ref.abs().max().item()
+    e3 = (_emulated_split_gemm(x, w, 2) - ref).abs().max().item() / scale
+    e6 = (_emulated_split_gemm(x, w, 3) - ref).abs().max().item() / scale
+    e32 = ((x @ w.t()).double() - ref).abs().max().item() / scale
+    assert e6 < 2e-7 and e6 <= e32 * 2       # at least as good as an fp32 GEMM
+    assert 1e-7 < e3 < 2e-5
+
+
+def test_split_planes_layout_and_exactness():
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(64, 64, generator=g)
+    flat = weights.split_planes(w)
+    assert flat.dtype == torch.float32 and flat.numel() == 3 * 64 * 64 // 2
+    bf = flat.view(torch.int16).view(torch.bfloat16).reshape(3, 64 // 16, 64, 16)   # [plane][slab][row][16]
+    rec = bf.float().sum(0).permute(1, 0, 2).reshape(64, 64)                        # hi + mid + lo
+    assert (rec - w).abs().max().item() <= 2 ** -23 * w.abs().max().item()         # 24 bits recovered
+    hi = bf[0].float().permute(1, 0, 2).reshape(64, 64)
+    assert torch.equal(hi, w.to(torch.bfloat16).float())
