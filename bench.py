@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--graphs-per-gpu", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (0 = skip cpu_baseline)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-library HIP-event brackets")
-    ap.add_argument("--precision", default="bf16x6", choices=["fp32", "bf16x3", "bf16x6"],
+    ap.add_argument("--precision", default="bf16x6", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
                     help="arithmetic of the E-row linears: exact fp32 MFMA, or fp32 split into 2/3 bf16 planes "
                          "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
     args = ap.parse_args()
@@ -171,14 +171,15 @@ def main():
             # one E-row linear [E,H] x [H,H]^T.  Algorithmic bytes: read X + write Y (+ read residual for the
             # per_layer_out linear = every second launch) -> 2.5 passes of E*H*4 on average.
             flops = 2.0 * E_local * H * H
-            n_prod = {"fp32": 1, "bf16x3": 3, "bf16x6": 6}[args.precision]
+            n_prod = {"fp32": 1, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3}[args.precision]
             mfma_peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
             mfma_tf = flops * n_prod / avg_s / 1e12          # matrix-core work actually issued
             bytes_alg = 2.5 * E_local * H * 4
             hbm_gbs = bytes_alg / avg_s / 1e9
             kname = ("linear_rows_kernel<256,256,16> (E-row linear, exact fp32 MFMA)" if args.precision == "fp32" else
-                     f"linear_rows_split_kernel<256,256,{2 if args.precision == 'bf16x3' else 3}> "
-                     f"(E-row linear, fp32 split into bf16 planes, {n_prod} MFMA products)")
+                     f"linear_rows_split_kernel<256,256,{3 if args.precision == 'bf16x6' else 2},"
+                     f"{'Fp16' if args.precision == 'fp16x3' else 'Bf16'}> "
+                     f"(E-row linear, fp32 split into 16-bit planes, {n_prod} MFMA products)")
             if mfma_tf / mfma_peak >= hbm_gbs / PEAK_HBM_GBS:
                 out["roofline"] = {"bound": "mfma", "achieved": mfma_tf, "peak": mfma_peak, "unit": "TFLOP/s",
                                    "frac": mfma_tf / mfma_peak, "traffic": None}

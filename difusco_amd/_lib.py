@@ -5,12 +5,12 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
-PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
-PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
+PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3 = 0, 1, 2, 3
+PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "fp16x3": PREC_FP16X3}
 
 # indices into difusco_weights_layout() (mirrors the enums of include/difusco_hip.h)
 W_GLOBAL = ["node_embed.weight", "node_embed.bias", "edge_embed.weight", "edge_embed.bias",

@@ -55,7 +55,7 @@ Layout make_layout(int H, int L, int C) {
   push(H); push(H);                       // out.0 (GroupNorm affine)
   push((int64_t)C * H); push(C);          // out.2 (1x1 conv)
   push(T2); push(T2); push(H);            // freqs, dimt_pos, dimt_scalar
-  push((int64_t)3 * H * H / 2);           // edge_embed bf16 planes (3 planes of H*H bf16)
+  push((int64_t)5 * H * H / 2);           // edge_embed split planes (3 bf16 + 2 fp16 planes of H*H)
   const int64_t layer0 = cur;
   for (int l = 0; l < L; ++l) {
     push((int64_t)4 * H * H); push((int64_t)4 * H);  // node4 = U|V|A|B
@@ -64,7 +64,7 @@ Layout make_layout(int H, int L, int C) {
     push((int64_t)H * T2); push(H);                   // time layer
     push(H); push(H);                                 // per_layer_out LN
     push((int64_t)H * H); push(H);                    // per_layer_out linear
-    push((int64_t)3 * H * H / 2); push((int64_t)3 * H * H / 2);  // bf16 planes of C and per_layer_out
+    push((int64_t)5 * H * H / 2); push((int64_t)5 * H * H / 2);  // split planes of C and per_layer_out
     if (l == 0) lo.layer_stride = cur - layer0;
   }
   lo.total = cur;
@@ -222,15 +222,15 @@ int difusco_denoise_step(const difusco_step_args* a) {
   auto G = [&](int id) { return W + lo.off[id]; };
   auto LW = [&](int l, int id) { return W + lo.off[DIFUSCO_W_GLOBAL_COUNT + l * DIFUSCO_WL_COUNT + id]; };
   hipStream_t st = (hipStream_t)a->stream;
-  if (a->precision < DIFUSCO_PREC_FP32 || a->precision > DIFUSCO_PREC_BF16X6)
+  if (a->precision < DIFUSCO_PREC_FP32 || a->precision > DIFUSCO_PREC_FP16X3)
     return fail(DIFUSCO_EINVAL, "unknown precision %d", a->precision);
-  const int n_planes = a->precision == DIFUSCO_PREC_BF16X3 ? 2 : 3;
   // E-row linear: exact fp32 MFMA or bf16 split planes, same contract
   auto edge_linear = [&](const float* x, const float* w, const float* planes, const float* b, const float* res,
                          float* y) -> hipError_t {
     if (a->precision == DIFUSCO_PREC_FP32) return linear_rows(x, w, b, res, y, E, H, H, H, st);
-    return linear_rows_split(x, reinterpret_cast<const unsigned short*>(planes), (long long)H * H, n_planes, b, res, y,
-                             E, H, H, H, st);
+    const unsigned short* pl = reinterpret_cast<const unsigned short*>(planes);
+    if (a->precision == DIFUSCO_PREC_FP16X3) pl += (long long)3 * H * H;   // fp16 planes follow the 3 bf16 planes
+    return linear_rows_split(x, pl, (long long)H * H, a->precision, b, res, y, E, H, H, H, st);
   };
 
   // PROF(category, call): HIP_TRY(call), bracketed by a pair of HIP events on `st` when profiling is on
@@ -306,12 +306,13 @@ int difusco_linear_rows(const float* x, const float* w, const float* bias, const
 int difusco_linear_rows_split(const float* x, const void* planes, int precision, const float* bias,
                               const float* residual, float* y, int64_t m, int k, int n_out, int64_t ldy, void* stream) {
   if (!x || !planes || !y) return fail(DIFUSCO_EINVAL, "null pointer");
-  if (precision != DIFUSCO_PREC_BF16X3 && precision != DIFUSCO_PREC_BF16X6)
-    return fail(DIFUSCO_EINVAL, "precision must be BF16X3 or BF16X6");
+  if (precision < DIFUSCO_PREC_BF16X3 || precision > DIFUSCO_PREC_FP16X3)
+    return fail(DIFUSCO_EINVAL, "precision must be BF16X3, BF16X6 or FP16X3");
   if (k != n_out || !(k == 64 || k == 128 || k == 256) || ldy < n_out)
     return fail(DIFUSCO_EINVAL, "split path needs k == n_out in {64,128,256}, ldy >= n_out");
-  HIP_TRY(difusco::linear_rows_split(x, reinterpret_cast<const unsigned short*>(planes), (long long)n_out * k,
-                                     precision == DIFUSCO_PREC_BF16X3 ? 2 : 3, bias, residual, y, m, k, n_out, ldy,
+  const unsigned short* pl = reinterpret_cast<const unsigned short*>(planes);
+  if (precision == DIFUSCO_PREC_FP16X3) pl += (long long)3 * n_out * k;
+  HIP_TRY(difusco::linear_rows_split(x, pl, (long long)n_out * k, precision, bias, residual, y, m, k, n_out, ldy,
                                      (hipStream_t)stream));
   return DIFUSCO_OK;
 }

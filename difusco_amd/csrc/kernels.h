@@ -7,7 +7,7 @@ namespace difusco {
 hipError_t linear_rows(const float* x, const float* w, const float* bias, const float* residual, float* y,
                        long long m, int k, int n_out, long long ldy, hipStream_t stream);
 
-hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int n_planes,
+hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int mode,
                              const float* bias, const float* residual, float* y, long long m, int k, int n_out,
                              long long ldy, hipStream_t stream);
 

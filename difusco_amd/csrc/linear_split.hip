@@ -8,6 +8,14 @@
 // so 6 products cost 6/16 of the exact-fp32 MFMA path and the E-row linears of the DIFUSCO layer
 // (difusco/models/gnn_encoder.py:104 `C`, :344 `per_layer_out[2]`, :395 `edge_embed`) become HBM-bound.
 //
+// A third mode decomposes into TWO fp16 planes (11+11 significand bits, 3 products): fp32-class accuracy
+// at half the matrix-core work of the 6-product bf16 mode, valid while |x| < 65504 (the operands here are
+// LayerNorm-bounded activations, the residual stream and weights).
+//
+// Inside every 16-wide k slab the two middle groups of 4 are swapped (slab position j holds
+// k = {0..3, 8..11, 4..7, 12..15}[j]) - the order in which a 32x32 MFMA accumulator hands 8 of its
+// registers to the next MFMA as a B operand (used by the fused layer kernel, edge_layer.hip).
+//
 // Same orientation as linear.hip (transposed: A = 32 weight rows, B = 32 data rows; a lane owns 4
 // consecutive output features of one data row per accumulator quad).  Weights arrive PRE-SPLIT from the
 // host (weights.py) as planes laid out [K/16 slabs][n_out rows][16 k] bf16, so a slab is one linear
@@ -23,16 +31,38 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
-// (a, b) -> packed bf16 pair (RNE) and the fp32 remainders
-__device__ __forceinline__ unsigned split_pair(float& a, float& b) {
-  v2f f = {a, b};
-  v2bf h = __builtin_convertvector(f, v2bf);
-  a -= (float)h[0];
-  b -= (float)h[1];
-  return __builtin_bit_cast(unsigned, h);
-}
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
-template <int K, int FB, int NS>
+// 16-bit element traits: (a, b) -> packed pair (RNE) + fp32 remainders; the matching MFMA
+struct Bf16 {
+  typedef v8bf frag;
+  __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
+    v2f f = {a, b};
+    v2bf h = __builtin_convertvector(f, v2bf);
+    a -= (float)h[0];
+    b -= (float)h[1];
+    return __builtin_bit_cast(unsigned, h);
+  }
+  __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct Fp16 {
+  typedef v8h frag;
+  __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
+    v2f f = {a, b};
+    v2h h = __builtin_convertvector(f, v2h);
+    a -= (float)h[0];
+    b -= (float)h[1];
+    return __builtin_bit_cast(unsigned, h);
+  }
+  __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int K, int FB, int NS, typename T>
 __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* __restrict__ X,
                                                                     const unsigned short* __restrict__ Wp,
                                                                     long long plane_stride,  // elements between planes
@@ -89,9 +119,10 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
       float a = xr[i][0], b = xr[i][1], c = xr[i][2], d = xr[i][3];                                   \
       _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                \
         v2u pk;                                                                                       \
-        pk[0] = split_pair(a, b);                                                                     \
-        pk[1] = split_pair(c, d);                                                                     \
-        *reinterpret_cast<v2u*>(Xs + (p * RB + row) * RS + c4 * 4) = pk;                              \
+        pk[0] = T::split_pair(a, b);                                                                  \
+        pk[1] = T::split_pair(c, d);                                                                  \
+        /* k group c4 goes to slab position group {0,2,1,3}[c4] */                                    \
+        *reinterpret_cast<v2u*>(Xs + (p * RB + row) * RS + (((c4 & 1) << 1) | (c4 >> 1)) * 4) = pk;   \
       }                                                                                               \
     }                                                                                                 \
     _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                  \
@@ -113,23 +144,24 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
   for (int kt = 0; kt < K; kt += BK) {
     const int kn = (kt + BK) < K ? kt + BK : kt;
     DIFUSCO_LOAD(kn)
-    v8bf xb[NS];
+    typedef typename T::frag frag;
+    frag xb[NS];
 #pragma unroll
-    for (int p = 0; p < NS; ++p) xb[p] = *reinterpret_cast<const v8bf*>(xrow + p * RB * RS);
+    for (int p = 0; p < NS; ++p) xb[p] = *reinterpret_cast<const frag*>(xrow + p * RB * RS);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      v8bf wa[NS];
+      frag wa[NS];
 #pragma unroll
-      for (int p = 0; p < NS; ++p) wa[p] = *reinterpret_cast<const v8bf*>(wrow + (p * FB + nb * 32) * RS);
+      for (int p = 0; p < NS; ++p) wa[p] = *reinterpret_cast<const frag*>(wrow + (p * FB + nb * 32) * RS);
       // smallest terms first
       if constexpr (NS == 3) {
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[2], xb[0], acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[2], acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb[1], acc[nb], 0, 0, 0);
+        acc[nb] = T::mfma(wa[2], xb[0], acc[nb]);
+        acc[nb] = T::mfma(wa[0], xb[2], acc[nb]);
+        acc[nb] = T::mfma(wa[1], xb[1], acc[nb]);
       }
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], xb[0], acc[nb], 0, 0, 0);
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[1], acc[nb], 0, 0, 0);
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], xb[0], acc[nb], 0, 0, 0);
+      acc[nb] = T::mfma(wa[1], xb[0], acc[nb]);
+      acc[nb] = T::mfma(wa[0], xb[1], acc[nb]);
+      acc[nb] = T::mfma(wa[0], xb[0], acc[nb]);
     }
     __syncthreads();
     DIFUSCO_STORE()
@@ -154,33 +186,36 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
   }
 }
 
-template <int K, int FB, int NS>
+template <int K, int FB, int NS, typename T>
 static hipError_t launch_split(const float* x, const unsigned short* wp, long long plane_stride, const float* bias,
                                const float* residual, float* y, long long m, int n_out, long long ldy, hipStream_t stream) {
   constexpr size_t lds = (size_t)NS * (128 + FB) * 24 * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_split_kernel<K, FB, NS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_split_kernel<K, FB, NS, T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid((unsigned)((m + 127) / 128), (unsigned)(n_out / FB));
-  hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
+  hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS, T>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
                      bias, residual, y, m, ldy);
   return hipGetLastError();
 }
 
-// wp: NS..3 planes, plane p at wp + p*plane_stride, each [K/16][n_out][16] bf16.  n_planes = 2 or 3.
-hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int n_planes,
+// wp: first plane of the chosen element type, plane p at wp + p*plane_stride, each [K/16][n_out][16]
+// (k-permuted).  mode: 1 = bf16 x 2 planes (3 products), 2 = bf16 x 3 planes (6 products),
+// 3 = fp16 x 2 planes (3 products).
+hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int mode,
                              const float* bias, const float* residual, float* y, long long m, int k, int n_out,
                              long long ldy, hipStream_t stream) {
   if (m <= 0) return hipSuccess;
-  if (n_planes != 2 && n_planes != 3) return hipErrorInvalidValue;
-#define DIFUSCO_SPLIT_CASE(KK, FBB)                                                                              \
-  if (k == KK && n_out % FBB == 0) {                                                                             \
-    return n_planes == 2 ? launch_split<KK, FBB, 2>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream) \
-                         : launch_split<KK, FBB, 3>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream); \
+  if (mode < 1 || mode > 3) return hipErrorInvalidValue;
+#define DIFUSCO_SPLIT_CASE(KK, FBB)                                                                                   \
+  if (k == KK && n_out % FBB == 0) {                                                                                  \
+    if (mode == 1) return launch_split<KK, FBB, 2, Bf16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream); \
+    if (mode == 2) return launch_split<KK, FBB, 3, Bf16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream); \
+    return launch_split<KK, FBB, 2, Fp16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream);               \
   }
   DIFUSCO_SPLIT_CASE(256, 256)
   DIFUSCO_SPLIT_CASE(128, 128)

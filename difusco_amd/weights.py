@@ -37,16 +37,31 @@ def constant_tables(hidden: int):
     return {"@time_freqs": freqs, "@dimt_pos": dim_t(half), "@dimt_scalar": dim_t(hidden)}
 
 
+_SLAB_ORDER = [0, 2, 1, 3]   # slab position group g holds k group _SLAB_ORDER[g] (middle groups of 4 swapped)
+
+
+def _slab_layout(p16: torch.Tensor, n_out: int, k: int) -> torch.Tensor:
+    """[n_out, k] 16-bit -> [k/16 slabs][n_out rows][16] with the k permutation of linear_split.hip."""
+    t = p16.reshape(n_out, k // 16, 4, 4)[:, :, _SLAB_ORDER, :]
+    return t.permute(1, 0, 2, 3).contiguous().reshape(-1)
+
+
 def split_planes(w: torch.Tensor) -> torch.Tensor:
-    """[n_out, k] fp32 -> the three bf16 planes hi | mid | lo (RNE), each laid out [k/16][n_out][16],
-    returned as a flat fp32-typed view (3*n_out*k/2 floats) ready to be copied into the blob."""
+    """[n_out, k] fp32 -> five 16-bit planes: bf16 hi | mid | lo, then fp16 hi | lo (all RNE, each the
+    rounding of what the previous planes left), every plane in the slab layout above.  Returned as a
+    flat fp32-typed view (5*n_out*k/2 floats) ready to be copied into the blob."""
     n_out, k = w.shape
     planes, rest = [], w.clone()
     for _ in range(3):
         p = rest.to(torch.bfloat16)
         rest = rest - p.float()
-        planes.append(p.reshape(n_out, k // 16, 16).permute(1, 0, 2).contiguous().reshape(-1))
-    return torch.cat(planes).view(torch.int16).view(torch.float32)
+        planes.append(_slab_layout(p.view(torch.int16), n_out, k))
+    rest = w.clone()
+    for _ in range(2):
+        p = rest.to(torch.float16)
+        rest = rest - p.float()
+        planes.append(_slab_layout(p.view(torch.int16), n_out, k))
+    return torch.cat(planes).view(torch.float32)
 
 
 def pack_state_dict(state) -> torch.Tensor:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 2
+#define DIFUSCO_ABI_VERSION 3
 
 enum {
   DIFUSCO_OK = 0,
@@ -39,7 +39,8 @@ enum { DIFUSCO_CATEGORICAL = 0, DIFUSCO_GAUSSIAN = 1 };
 enum {
   DIFUSCO_PREC_FP32 = 0,   /* E-row linears on v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fma chain) */
   DIFUSCO_PREC_BF16X3 = 1, /* 2 bf16 planes, 3 products: ~2^-17 relative per product                    */
-  DIFUSCO_PREC_BF16X6 = 2  /* 3 bf16 planes, 6 products: all 24 significand bits, fp32-class accuracy    */
+  DIFUSCO_PREC_BF16X6 = 2, /* 3 bf16 planes, 6 products: all 24 significand bits, fp32-class accuracy    */
+  DIFUSCO_PREC_FP16X3 = 3  /* 2 fp16 planes, 3 products: 22 significand bits, needs |x| < 65504          */
 };
 enum {
   DIFUSCO_RAND_NONE = 0,     /* no draw: categorical final step (target_t == 0) or DDIM */
@@ -77,11 +78,14 @@ enum {                       /* per layer l, index = GLOBAL_COUNT + l*LAYER_COUN
   DIFUSCO_WL_C_PLANES, DIFUSCO_WL_OUT_PLANES, /* bf16 split planes of C / per_layer_out[l].2 */
   DIFUSCO_WL_COUNT
 };
-/* "*_PLANES" entries: the [H,H] weight w decomposed on the host into three bf16 planes
- *   hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid)      (round to nearest even)
- * stored back to back (plane stride H*H bf16 elements), each plane laid out [H/16 slabs][H rows][16 k]
- * (slab s, row f, j  <->  w[f][16 s + j]).  3*H*H bf16 = 1.5*H*H floats of blob space per matrix.
- * They feed the split-precision MFMA path selected by difusco_step_args.precision. */
+/* "*_PLANES" entries: the [H,H] weight w decomposed on the host into five 16-bit planes
+ *   bf16: hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid)      (round to nearest even)
+ *   fp16: hi = fp16(w), lo = fp16(w - hi)
+ * stored back to back in that order (plane stride H*H elements), each plane laid out
+ * [H/16 slabs][H rows][16] with slab position j holding k = 16 s + {0..3, 8..11, 4..7, 12..15}[j]
+ * (the order in which an MFMA accumulator feeds the next MFMA, see linear_split.hip).
+ * 5*H*H 16-bit elements = 2.5*H*H floats of blob space per matrix.  They feed the split-precision MFMA
+ * paths selected by difusco_step_args.precision. */
 /* Fills offsets[0 .. GLOBAL_COUNT + n_layers*WL_COUNT) (floats from blob start) and *total_floats.
  * Returns the number of entries, or a negative error. */
 int difusco_weights_layout(int hidden, int n_layers, int out_channels,
@@ -162,9 +166,8 @@ int difusco_denoise_step(const difusco_step_args* args);
  * k in {32,64,128,256}; n_out multiple of 32.  fp32 MFMA (v_mfma_f32_32x32x2_f32). */
 int difusco_linear_rows(const float* x, const float* w, const float* bias, const float* residual,
                         float* y, int64_t m, int k, int n_out, int64_t ldy, void* stream);
-/* Same contract on the split-precision path: `planes` = 3 bf16 planes of W[n_out,k] in the *_PLANES
- * layout above (plane stride n_out*k elements); precision = DIFUSCO_PREC_BF16X3 | DIFUSCO_PREC_BF16X6.
- * k == n_out in {64,128,256}. */
+/* Same contract on the split-precision path: `planes` = the five 16-bit planes of W[n_out,k] in the
+ * *_PLANES layout above; precision = DIFUSCO_PREC_BF16X3 | _BF16X6 | _FP16X3.  k == n_out in {64,128,256}. */
 int difusco_linear_rows_split(const float* x, const void* planes, int precision, const float* bias,
                               const float* residual, float* y, int64_t m, int k, int n_out, int64_t ldy,
                               void* stream);

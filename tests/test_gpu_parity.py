@@ -81,7 +81,7 @@ def test_linear_rows_in_place_residual(dev, L):
     assert (ed.cpu().double() - ref).abs().max().item() < 5e-5
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16x6", 6e-7)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16x6", 6e-7), ("fp16x3", 2e-6)])
 @pytest.mark.parametrize("m,k", [(1, 256), (127, 256), (4099, 256), (300, 128), (77, 64)])
 def test_linear_rows_split(dev, L, prec, tol, m, k):
     """Split-precision bf16 MFMA path (3 or 6 products) against fp64; error relative to max|Y|."""
@@ -329,7 +329,7 @@ def test_golden_mis(dev, golden_dir):
         assert np.abs(out.cpu().numpy() - z[f"gau{i}_out"]).max() < TOL
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3", "fp16x3"])
 @pytest.mark.parametrize("H,Lyr,N,K,G", [(256, 3, 60, 10, 2), (256, 12, 100, 20, 1), (128, 2, 33, 5, 3)])
 def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
     """H=256 / 12 layers (the production width) against the oracle on seeded synthetic inputs,
@@ -368,7 +368,7 @@ def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3", "fp16x3"])
 def test_oracle_tsp_gaussian_full_width(dev, prec):
     from difusco_amd import TSPModel
     H, Lyr, N, K = 256, 4, 80, 12

@@ -219,9 +219,13 @@ def test_split_planes_layout_and_exactness():
     g = torch.Generator().manual_seed(1)
     w = torch.randn(64, 64, generator=g)
     flat = weights.split_planes(w)
-    assert flat.dtype == torch.float32 and flat.numel() == 3 * 64 * 64 // 2
-    bf = flat.view(torch.int16).view(torch.bfloat16).reshape(3, 64 // 16, 64, 16)   # [plane][slab][row][16]
-    rec = bf.float().sum(0).permute(1, 0, 2).reshape(64, 64)                        # hi + mid + lo
-    assert (rec - w).abs().max().item() <= 2 ** -23 * w.abs().max().item()         # 24 bits recovered
-    hi = bf[0].float().permute(1, 0, 2).reshape(64, 64)
-    assert torch.equal(hi, w.to(torch.bfloat16).float())
+    assert flat.dtype == torch.float32 and flat.numel() == 5 * 64 * 64 // 2
+    raw = flat.view(torch.int16).reshape(5, 64 // 16, 64, 4, 4)        # [plane][slab][row][pos group][4]
+    inv = [0, 2, 1, 3]                                                 # the permutation is an involution
+    nat = raw[:, :, :, inv, :].permute(0, 2, 1, 3, 4).reshape(5, 64, 64)   # back to [plane][row][k]
+    bf = nat[:3].view(torch.bfloat16).float()
+    fp = nat[3:].view(torch.float16).float()
+    assert (bf.sum(0) - w).abs().max().item() <= 2 ** -23 * w.abs().max().item()     # 24 bits recovered
+    assert torch.equal(bf[0], w.to(torch.bfloat16).float())
+    assert torch.equal(fp[0], w.to(torch.float16).float())
+    assert (fp.sum(0) - w).abs().max().item() <= 2 ** -21 * w.abs().max().item()     # 22 bits recovered
