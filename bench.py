@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--graphs-per-gpu", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (0 = skip cpu_baseline)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-library HIP-event brackets")
-    ap.add_argument("--precision", default="bf16x6", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
+    ap.add_argument("--no-fusion", action="store_true", help="unfused kernel sequence (A/B against the fused layer kernel)")
+    ap.add_argument("--precision", default="fp16x3", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
                     help="arithmetic of the E-row linears: exact fp32 MFMA, or fp32 split into 2/3 bf16 planes "
                          "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
     args = ap.parse_args()
@@ -100,9 +101,9 @@ def main():
     # frozen weights: rank 0 creates, RCCL broadcast of the packed blob over xGMI
     params = random_state_dict(H, LAYERS, 2, seed=20240926) if rank == 0 or world == 1 else None
     if world > 1:
-        engine = engine_from_broadcast(params, device, src=0, precision=args.precision)
+        engine = engine_from_broadcast(params, device, src=0, precision=args.precision, fused=not args.no_fusion)
     else:
-        engine = DenoiseEngine(params, device=device, precision=args.precision)
+        engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion)
     margs = dict(diffusion_type="categorical", diffusion_schedule="linear", diffusion_steps=1000,
                  inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn,
                  n_layers=LAYERS, hidden_dim=H)
@@ -163,20 +164,25 @@ def main():
                                    f"{args.graphs_per_gpu} graphs per GPU (global batch {G_total}), H={H}, {LAYERS} layers",
                        "graphs_per_gpu": args.graphs_per_gpu, "global_batch": G_total, "nodes": args.nodes,
                        "knn": args.knn, "edges_per_graph": args.nodes * args.knn, "gn_stats": GN_STATS_MODE,
-                       "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision},
+                       "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision,
+                       "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3")},
         }
         if prof is not None and prof["launches"][0] > 0:
             n_lin = prof["launches"][0]
             avg_s = prof["ms"][0] / n_lin * 1e-3
             # one E-row linear [E,H] x [H,H]^T.  Algorithmic bytes: read X + write Y (+ read residual for the
             # per_layer_out linear = every second launch) -> 2.5 passes of E*H*4 on average.
-            flops = 2.0 * E_local * H * H
+            fused = (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3")
+            flops = (4.0 if fused else 2.0) * E_local * H * H     # fused: both E-row GEMMs of the layer in one launch
             n_prod = {"fp32": 1, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3}[args.precision]
             mfma_peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
             mfma_tf = flops * n_prod / avg_s / 1e12          # matrix-core work actually issued
-            bytes_alg = 2.5 * E_local * H * 4
+            bytes_alg = (2.0 if fused else 2.5) * E_local * H * 4   # fused: e read once + written once per layer
             hbm_gbs = bytes_alg / avg_s / 1e9
-            kname = ("linear_rows_kernel<256,256,16> (E-row linear, exact fp32 MFMA)" if args.precision == "fp32" else
+            kname = (f"edge_layer_fused_kernel<{'FFp16' if args.precision == 'fp16x3' else 'FBf16'}> (whole edge pass of a "
+                     f"layer: 2 chained E-row GEMMs, 3 MFMA products each, gate, 2 LayerNorms, neighbour-sum pieces)"
+                     if fused else
+                     "linear_rows_kernel<256,256,16> (E-row linear, exact fp32 MFMA)" if args.precision == "fp32" else
                      f"linear_rows_split_kernel<256,256,{3 if args.precision == 'bf16x6' else 2},"
                      f"{'Fp16' if args.precision == 'fp16x3' else 'Bf16'}> "
                      f"(E-row linear, fp32 split into 16-bit planes, {n_prod} MFMA products)")

@@ -5,7 +5,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
@@ -42,7 +42,8 @@ class StepArgs(ctypes.Structure):
         ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64),
         ("xt_out", ctypes.c_void_p), ("pred_out", ctypes.c_void_p), ("prob_out", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("stream", ctypes.c_void_p),
-        ("precision", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("precision", ctypes.c_int32), ("no_fusion", ctypes.c_int32),
+        ("row", ctypes.c_void_p),
     ]
 
 
@@ -73,6 +74,9 @@ def lib():
     L.difusco_denoise_step.argtypes = [ctypes.POINTER(StepArgs)]
     L.difusco_linear_rows.argtypes = [f32p, f32p, f32p, f32p, f32p, i64, i32, i32, i64, vp]
     L.difusco_linear_rows_split.argtypes = [f32p, vp, i32, f32p, f32p, f32p, i64, i32, i32, i64, vp]
+    L.difusco_fused_scratch_bytes.restype = ctypes.c_size_t
+    L.difusco_fused_scratch_bytes.argtypes = [i32, i32]
+    L.difusco_edge_layer_fused.argtypes = [i32, i32, i32, vp, vp, vp, f32p, f32p, f32p, vp, vp] + [f32p] * 9 + [i32, vp, vp]
     L.difusco_edge_gate_aggregate.argtypes = [i32, i32, vp, vp, f32p, f32p, f32p] + [f32p] * 7 + [i32, vp]
     L.difusco_categorical_posterior.argtypes = [f32p, f32p, ctypes.POINTER(ctypes.c_float), i32, f32p,
                                                 ctypes.c_uint64, ctypes.c_uint64, f32p, f32p, i64, vp]

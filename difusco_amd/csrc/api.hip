@@ -72,10 +72,13 @@ Layout make_layout(int H, int L, int C) {
 }
 
 struct Workspace {
-  float *h, *node4, *e, *tmp, *tbias, *table_in, *table, *stats;
+  float *h, *node4, *e, *tmp, *tbias, *table_in, *table, *stats, *part, *direct;
   double* partial;
   size_t bytes;
 };
+
+// pieces of the neighbour sum written by the fused edge kernel: 2 per 32-edge tile (4 tiles per workgroup)
+size_t fused_part_floats(int64_t E) { return (size_t)((E + 127) / 128) * 4 * 2 * 256; }
 
 Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk) {
   Workspace w;
@@ -94,6 +97,8 @@ Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk)
   w.table = (float*)take(sizeof(float) * 2 * H);
   w.stats = (float*)take(sizeof(float) * S * 64);
   w.partial = (double*)take(sizeof(double) * (size_t)S * nblk * 64);
+  w.part = (float*)take(H == 256 ? sizeof(float) * fused_part_floats(E) : 0);
+  w.direct = (float*)take(H == 256 ? sizeof(float) * N * H : 0);
   w.bytes = cur;
   return w;
 }
@@ -271,9 +276,27 @@ int difusco_denoise_step(const difusco_step_args* a) {
   }
 
   // the GNN layers (gnn_encoder.py:425-449)
+  const bool fused = H == 256 && !a->no_fusion && E > 0 &&
+                     (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
+  if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
+  const long long split_off = a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0;  // fp16 planes follow bf16
   for (int l = 0; l < L; ++l) {
     PROF(PROF_LINEAR_NODE, linear_rows(ws.h, LW(l, DIFUSCO_WL_NODE4_W), LW(l, DIFUSCO_WL_NODE4_B), nullptr, ws.node4, N,
                                        H, 4 * H, 4 * H, st))
+    if (fused) {
+      PROF(PROF_LINEAR_EDGE,
+           launch_edge_layer_fused(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,
+                                   reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_C_PLANES)) + split_off,
+                                   reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_OUT_PLANES)) + split_off,
+                                   (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
+                                   LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
+                                   LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
+                                   st))
+      PROF(PROF_GATE, launch_node_finalize((int)N, (int)E, a->rowptr, ws.node4, ws.part, ws.direct, ws.h,
+                                           LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
+                                           ws.tbias + (size_t)l * H, tsp ? 1 : 0, st))
+      continue;
+    }
     PROF(PROF_LINEAR_EDGE, edge_linear(ws.e, LW(l, DIFUSCO_WL_C_W), LW(l, DIFUSCO_WL_C_PLANES), LW(l, DIFUSCO_WL_C_B),
                                        nullptr, ws.tmp))
     PROF(PROF_GATE, launch_edge_gate_aggregate(H, (int)N, a->rowptr, a->col, ws.node4, ws.tmp, ws.h,
@@ -326,6 +349,36 @@ int difusco_edge_gate_aggregate(int hidden, int n_nodes, const int32_t* rowptr, 
     return fail(DIFUSCO_EINVAL, "null pointer");
   HIP_TRY(difusco::launch_edge_gate_aggregate(hidden, n_nodes, rowptr, col, node4, ce_act, h, norm_h_w, norm_h_b, norm_e_w,
                                               norm_e_b, out_ln_w, out_ln_b, tbias, time_on_edge, (hipStream_t)stream));
+  return DIFUSCO_OK;
+}
+
+size_t difusco_fused_scratch_bytes(int n_nodes, int n_edges) {
+  if (n_nodes < 0 || n_edges < 0) return 0;
+  return sizeof(float) * (fused_part_floats(n_edges) + (size_t)n_nodes * 256) + 256;
+}
+
+int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int32_t* rowptr, const int32_t* row,
+                             const int32_t* col, const float* node4, float* e, float* h, const void* planes_c,
+                             const void* planes_o, const float* b_c, const float* norm_h_w, const float* norm_h_b,
+                             const float* norm_e_w, const float* norm_e_b, const float* out_ln_w,
+                             const float* out_ln_b, const float* b_out, const float* tbias, int time_on_edge,
+                             void* scratch, void* stream) {
+  if (precision != DIFUSCO_PREC_BF16X3 && precision != DIFUSCO_PREC_FP16X3)
+    return fail(DIFUSCO_EINVAL, "fused kernel: precision must be BF16X3 or FP16X3");
+  if (!rowptr || !row || !col || !node4 || !e || !h || !planes_c || !planes_o || !b_c || !norm_h_w || !norm_h_b ||
+      !norm_e_w || !norm_e_b || !out_ln_w || !out_ln_b || !b_out || !tbias || !scratch)
+    return fail(DIFUSCO_EINVAL, "null pointer");
+  const long long off = precision == DIFUSCO_PREC_FP16X3 ? 3LL * 256 * 256 : 0;
+  float* part = reinterpret_cast<float*>(scratch);
+  float* direct = part + (fused_part_floats(n_edges) + 63) / 64 * 64;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(difusco::launch_edge_layer_fused(precision, e, node4, row, col, n_edges,
+                                           reinterpret_cast<const unsigned short*>(planes_c) + off,
+                                           reinterpret_cast<const unsigned short*>(planes_o) + off, 256LL * 256, b_c,
+                                           norm_e_w, norm_e_b, tbias, out_ln_w, out_ln_b, b_out, time_on_edge, part,
+                                           direct, st));
+  HIP_TRY(difusco::launch_node_finalize(n_nodes, n_edges, rowptr, node4, part, direct, h, norm_h_w, norm_h_b, tbias,
+                                        time_on_edge, st));
   return DIFUSCO_OK;
 }
 

@@ -1,0 +1,479 @@
+// Fused edge pass of one DIFUSCO GNN layer for gfx950 (H = 256): the edge state e is read ONCE and
+// written ONCE per layer.
+//
+//   Ce    = C e                                    gnn_encoder.py:104           GEMM 1 (matrix cores)
+//   e'    = Ah[j] + Bh[i] + (Ce + b_C)             :110
+//   m     = sigmoid(e') * Vh[j]  -> sum over the edges of centre node i          :112,:115,:163,:177-191
+//   y     = ReLU(LN_e(e')) (+ t_l, TSP)            :131,:135,:445
+//   a     = SiLU(LN_o(y))                          per_layer_out[l][0:2] :339-342
+//   e    += W_o a + b_o                            per_layer_out[l][2] :344, residual :449   GEMM 2
+//
+// Chained, transposed MFMA.  Both GEMMs are computed as D[f][edge] = sum_k W[f][k] X[edge][k] (A operand =
+// 32 weight rows, B operand = 32 edges), so in the 32x32 accumulator a lane owns, for ITS edge (lane&31),
+// the features {32 nb + 8 g + 4 hh + 0..3} - half of the 256 features, the other half sits in lane+32.
+//   * LayerNorm over the 256 features of an edge = in-lane sum over 128 registers + ONE cross-half exchange.
+//   * Eight consecutive accumulator registers of a block are exactly the B operand (8 k values per lane
+//     half) of a 32x32x16 MFMA: the epilogued accumulators of GEMM 1 feed GEMM 2 straight from registers,
+//     no LDS round trip.  The weight planes are stored in that k order (weights.py: slab position order
+//     {0..3, 8..11, 4..7, 12..15}).
+//   * fp32 operands are split into two 16-bit planes (fp16: 22 significand bits, or bf16) and multiplied
+//     with 3 MFMA products (hi*hi, hi*lo, lo*hi), accumulated in fp32 (see linear_split.hip).
+// A workgroup = 4 waves = 128 edges; a wave owns a 32-edge tile end to end.  Weights stream through LDS in
+// 16 KiB stages ([256 rows][16 k] x 2 planes for GEMM 1, [128 rows][32 k] x 2 planes for each output half
+// of GEMM 2), double buffered, one barrier per stage; the 32-byte rows are XOR-swizzled so every 16-lane
+// group of ds_read_b128 hits 16 distinct 16-byte bank slots without padding.  GEMM 2 runs in two halves of
+// 128 output features (64 accumulator registers) so that act planes (128) + accumulators fit 256 VGPRs
+// and two workgroups share a CU: one wave's VALU epilogue overlaps the other's MFMA phase.
+//
+// Neighbour sum.  The gated messages m of a tile are transposed through a wave-private LDS scratch
+// (64 features per round) and summed per centre-node segment by lanes = features.  A segment that is
+// the first or last of its tile may continue in the neighbouring tile: it goes to part[tile][0|1];
+// segments strictly inside a tile are complete and go to direct[node].  node_finalize_kernel adds the
+// pieces of each node in tile order - deterministic, no atomics.
+#include "common.h"
+#include "kernels.h"
+
+namespace difusco {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+struct FBf16 {
+  typedef v8bf frag;
+  __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
+    v2f f = {a, b};
+    v2bf h = __builtin_convertvector(f, v2bf);
+    a -= (float)h[0];
+    b -= (float)h[1];
+    return __builtin_bit_cast(unsigned, h);
+  }
+  __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct FFp16 {
+  typedef v8h frag;
+  __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
+    v2f f = {a, b};
+    v2h h = __builtin_convertvector(f, v2h);
+    a -= (float)h[0];
+    b -= (float)h[1];
+    return __builtin_bit_cast(unsigned, h);
+  }
+  __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// eight fp32 -> two planes of eight 16-bit values (hi, lo)
+template <typename T>
+__device__ __forceinline__ void split8(const float (&x)[8], typename T::frag& hi, typename T::frag& lo) {
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = x[q];
+  v4u h, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h[q] = T::split_pair(v[2 * q], v[2 * q + 1]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) l[q] = T::split_pair(v[2 * q], v[2 * q + 1]);
+  hi = __builtin_bit_cast(typename T::frag, h);
+  lo = __builtin_bit_cast(typename T::frag, l);
+}
+
+namespace fused {
+constexpr int H = 256;
+constexpr int PLANE = 256 * 16;          // 16-bit elements per plane per stage
+constexpr int BUF = 2 * PLANE;           // one stage buffer: 2 planes
+constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregation scratch (64 + 4 pad)
+constexpr int LDS_W = 2 * BUF * 2;       // bytes: 2 buffers x 2 planes x 8 KiB           = 32768
+constexpr int LDS_P = 7 * H * 4;         // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O        =  7168
+constexpr int LDS_S = 4 * 32 * SCR_STRIDE * 4;  // bytes: 4 waves x 32 edges x 68 floats  = 34816
+constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;  // 74752 <= 80 KiB -> two workgroups per CU
+enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT };
+}  // namespace fused
+
+// LDS element offset of (entry, half) inside a plane: 32-byte rows, halves swapped on odd 8-row groups
+__device__ __forceinline__ int wslot(int entry, int half) { return entry * 16 + ((half ^ ((entry >> 3) & 1)) << 3); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
+    float* e, const float* __restrict__ node4, const int* __restrict__ row, const int* __restrict__ col, int n_edges,
+    const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
+    const float* __restrict__ b_c, const float* __restrict__ g_e, const float* __restrict__ b_e,
+    const float* __restrict__ tbias, const float* __restrict__ g_o, const float* __restrict__ b_o,
+    const float* __restrict__ b_out, int time_on_edge, float* __restrict__ part, float* __restrict__ direct) {
+  using namespace fused;
+  typedef typename T::frag frag;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* wbuf = reinterpret_cast<unsigned short*>(smem_raw);
+  float* prm = reinterpret_cast<float*>(smem_raw + LDS_W);
+  float* scr_all = reinterpret_cast<float*>(smem_raw + LDS_W + LDS_P);
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x * 4 + wave;
+  const int s_base = tile * 32;
+  const int s_raw = s_base + l31;
+  const bool valid = s_raw < n_edges;
+  const int s = valid ? s_raw : n_edges - 1;
+  float* erow = e + (long long)s * H;
+  float* scr = scr_all + wave * 32 * SCR_STRIDE;
+
+  // layer parameters -> LDS (thread = feature)
+  prm[P_BC * H + tid] = b_c[tid];
+  prm[P_GE * H + tid] = g_e[tid];
+  prm[P_BE * H + tid] = b_e[tid];
+  prm[P_T * H + tid] = time_on_edge ? tbias[tid] : 0.0f;
+  prm[P_GO * H + tid] = g_o[tid];
+  prm[P_BO * H + tid] = b_o[tid];
+  prm[P_BOUT * H + tid] = b_out[tid];
+
+  // ---- weight stage streaming ---------------------------------------------------------------------
+  // stage t < 16 : GEMM 1, slab t of C, entry = weight row.
+  // stage 16 + u : GEMM 2, output half hf = u >> 3, slabs 2 kk, 2 kk + 1 (kk = u & 7) of W_o,
+  //                entry = ksl * 128 + (row - 128 hf).
+  v4u wr[2][2];
+  auto stage_src = [&](int t, int entry) -> const unsigned short* {
+    if (t < 16) return c_planes + ((long long)t * 256 + entry) * 16;
+    const int u = t - 16, hf = u >> 3, kk = u & 7;
+    return o_planes + ((long long)(2 * kk + (entry >> 7)) * 256 + 128 * hf + (entry & 127)) * 16;
+  };
+#define FUSED_LOAD_STAGE(t)                                                                        \
+  {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+      const int c = tid + 256 * i;                                                                 \
+      const unsigned short* src = stage_src((t), c >> 1) + (c & 1) * 8;                            \
+      wr[0][i] = *reinterpret_cast<const v4u*>(src);                                               \
+      wr[1][i] = *reinterpret_cast<const v4u*>(src + plane_stride);                                \
+    }                                                                                              \
+  }
+#define FUSED_STORE_STAGE(t)                                                                       \
+  {                                                                                                \
+    unsigned short* dst = wbuf + ((t) & 1) * BUF;                                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+      const int c = tid + 256 * i;                                                                 \
+      const int off = wslot(c >> 1, c & 1);                                                        \
+      *reinterpret_cast<v4u*>(dst + off) = wr[0][i];                                               \
+      *reinterpret_cast<v4u*>(dst + PLANE + off) = wr[1][i];                                       \
+    }                                                                                              \
+  }
+
+  FUSED_LOAD_STAGE(0)
+  FUSED_STORE_STAGE(0)
+
+  const int j = col[s];
+  const int i_node = row[s];
+  const float* nj = node4 + (long long)j * 4 * H;       // rows U | V | A | B
+  const float* ni = node4 + (long long)i_node * 4 * H;
+
+  v16f acc1[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.0f;
+
+  // B operand of GEMM 1, slab 0: k offsets {4hh..4hh+3, 8+4hh..8+4hh+3}
+  v4f b0 = *reinterpret_cast<const v4f*>(erow + 4 * hh);
+  v4f b1 = *reinterpret_cast<const v4f*>(erow + 8 + 4 * hh);
+  __syncthreads();
+
+  const int a_off = wslot(l31, hh);   // entry = 32 nb + l31 : (entry >> 3) & 1 == (l31 >> 3) & 1
+
+  // ================================ GEMM 1 ==========================================================
+  for (int ks = 0; ks < 16; ++ks) {
+    FUSED_LOAD_STAGE(ks + 1)          // ks == 15 prefetches stage 16 = first stage of GEMM 2
+    const int kn = ks < 15 ? ks + 1 : ks;
+    const v4f n0 = *reinterpret_cast<const v4f*>(erow + 16 * kn + 4 * hh);
+    const v4f n1 = *reinterpret_cast<const v4f*>(erow + 16 * kn + 8 + 4 * hh);
+    const float xs[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    frag xh, xl;
+    split8<T>(xs, xh, xl);
+    const unsigned short* wb = wbuf + (ks & 1) * BUF + a_off;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const frag wh = *reinterpret_cast<const frag*>(wb + nb * 32 * 16);
+      const frag wl = *reinterpret_cast<const frag*>(wb + PLANE + nb * 32 * 16);
+      acc1[nb] = T::mfma(wl, xh, acc1[nb]);
+      acc1[nb] = T::mfma(wh, xl, acc1[nb]);
+      acc1[nb] = T::mfma(wh, xh, acc1[nb]);
+    }
+    FUSED_STORE_STAGE(ks + 1)
+    __syncthreads();
+    b0 = n0;
+    b1 = n1;
+  }
+
+  // ================================ epilogue 1 =======================================================
+  // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3
+  float s1 = 0.0f;
+  const float vmask = valid ? 1.0f : 0.0f;   // lanes past the last edge contribute nothing to the neighbour sum
+#pragma unroll
+  for (int rnd = 0; rnd < 4; ++rnd) {          // 64 features per round: blocks 2 rnd, 2 rnd + 1
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq) {
+      const int nb = 2 * rnd + nq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fb = 32 * nb + 8 * g + 4 * hh;
+        const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
+        const v4f ah = *reinterpret_cast<const v4f*>(nj + 2 * H + fb);
+        const v4f bh = *reinterpret_cast<const v4f*>(ni + 3 * H + fb);
+        const v4f vh = *reinterpret_cast<const v4f*>(nj + H + fb);
+        v4f m;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float ce = acc1[nb][4 * g + q] + bc[q];
+          const float ev = (ah[q] + bh[q]) + ce;
+          acc1[nb][4 * g + q] = ev;
+          s1 += ev;
+          m[q] = sigmoidf_(ev) * vh[q] * vmask;
+        }
+        *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // scratch is wave private: LDS ops of one wave complete in order
+    // segmented column sums: lane = feature 64 rnd + lane, walk the 32 edges of the tile
+    {
+      const int f = 64 * rnd + lane;
+      float accv = 0.0f;
+      int prev = -1;       // centre node of the running segment (wave-uniform)
+      int seg = 0;         // 0: first segment of the tile, 1: later
+#pragma unroll 4
+      for (int k = 0; k < 32; ++k) {
+        const int sk = s_base + k;
+        if (sk >= n_edges) break;                         // uniform
+        const int node = row[sk];                         // uniform scalar load
+        if (k > 0 && node != prev) {
+          // close the running segment: the first one may continue from the previous tile
+          if (seg == 0) part[((long long)tile * 2 + 0) * H + f] = accv;
+          else direct[(long long)prev * H + f] = accv;
+          accv = 0.0f;
+          seg = 1;
+        }
+        prev = node;
+        accv += scr[k * SCR_STRIDE + lane];
+      }
+      // the last segment of the tile may continue into the next tile
+      if (prev >= 0) part[((long long)tile * 2 + (seg == 0 ? 0 : 1)) * H + f] = accv;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
+  constexpr float inv_h = 1.0f / 256.0f;
+  const float mean1 = (s1 + __shfl_xor(s1, 32, 64)) * inv_h;
+  float q1 = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = acc1[nb][r] - mean1;
+      acc1[nb][r] = d;
+      q1 += d * d;
+    }
+  const float rstd1 = 1.0f / sqrtf((q1 + __shfl_xor(q1, 32, 64)) * inv_h + 1e-5f);
+  float s2 = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int fb = 32 * nb + 8 * g + 4 * hh;
+      const v4f ge = *reinterpret_cast<const v4f*>(prm + P_GE * H + fb);
+      const v4f be = *reinterpret_cast<const v4f*>(prm + P_BE * H + fb);
+      const v4f tb = *reinterpret_cast<const v4f*>(prm + P_T * H + fb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float y = acc1[nb][4 * g + q] * rstd1 * ge[q] + be[q];
+        y = (y > 0.0f ? y : 0.0f) + tb[q];
+        acc1[nb][4 * g + q] = y;
+        s2 += y;
+      }
+    }
+  const float mean2 = (s2 + __shfl_xor(s2, 32, 64)) * inv_h;
+  float q2 = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = acc1[nb][r] - mean2;
+      acc1[nb][r] = d;
+      q2 += d * d;
+    }
+  const float rstd2 = 1.0f / sqrtf((q2 + __shfl_xor(q2, 32, 64)) * inv_h + 1e-5f);
+
+  // activation -> 16-bit planes, kept in registers as the B operands of GEMM 2
+  frag ah_[8][2], al_[8][2];      // [block nb][register group rg] : slab 2 nb + rg
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+      float a8[8];
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        const int g = 2 * rg + g2;
+        const int fb = 32 * nb + 8 * g + 4 * hh;
+        const v4f go = *reinterpret_cast<const v4f*>(prm + P_GO * H + fb);
+        const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BO * H + fb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float z = acc1[nb][4 * g + q] * rstd2 * go[q] + bo[q];
+          a8[4 * g2 + q] = z * sigmoidf_(z);
+        }
+      }
+      split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
+    }
+
+  // ================================ GEMM 2 (two output halves) =======================================
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    v16f acc2[4];
+#pragma unroll
+    for (int nbp = 0; nbp < 4; ++nbp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[nbp][r] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int t = 16 + hf * 8 + kk;
+      if (t < 31) FUSED_LOAD_STAGE(t + 1)
+      const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
+#pragma unroll
+      for (int ksl = 0; ksl < 2; ++ksl) {
+        const int sl = 2 * kk + ksl;          // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
+        const frag xh = ah_[sl >> 1][sl & 1];
+        const frag xl = al_[sl >> 1][sl & 1];
+#pragma unroll
+        for (int nbp = 0; nbp < 4; ++nbp) {
+          const int ent = (ksl * 128 + nbp * 32) * 16;   // entry = ksl*128 + 32 nbp + l31
+          const frag wh = *reinterpret_cast<const frag*>(wb + ent);
+          const frag wl = *reinterpret_cast<const frag*>(wb + PLANE + ent);
+          acc2[nbp] = T::mfma(wl, xh, acc2[nbp]);
+          acc2[nbp] = T::mfma(wh, xl, acc2[nbp]);
+          acc2[nbp] = T::mfma(wh, xh, acc2[nbp]);
+        }
+      }
+      if (t < 31) {
+        FUSED_STORE_STAGE(t + 1)
+        __syncthreads();
+      }
+    }
+    // e <- e + W_o a + b_o  for the features 128 hf + 32 nbp + 8 g + 4 hh + 0..3 of this lane's edge
+    if (valid) {
+#pragma unroll
+      for (int nbp = 0; nbp < 4; ++nbp)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int fo = 128 * hf + 32 * nbp + 8 * g + 4 * hh;
+          const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BOUT * H + fo);
+          const v4f ein = *reinterpret_cast<const v4f*>(erow + fo);
+          v4f v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ein[q] + (acc2[nbp][4 * g + q] + bo[q]);
+          *reinterpret_cast<v4f*>(erow + fo) = v;
+        }
+    }
+  }
+#undef FUSED_LOAD_STAGE
+#undef FUSED_STORE_STAGE
+}
+
+// ------------------------------------------------------------------------------------------------
+// node update after the fused edge pass:  h_i += ReLU(LN_h(Uh_i + sum_j gate*Vh_j)) (+ t, MIS)
+// (gnn_encoder.py:115,123,134,447-448).  One wavefront per node; the neighbour sum is assembled from the
+// per-tile pieces written by edge_layer_fused_kernel, in tile order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_edges, const int* __restrict__ rowptr,
+                                                            const float* __restrict__ node4,
+                                                            const float* __restrict__ part,
+                                                            const float* __restrict__ direct, float* h,
+                                                            const float* __restrict__ nh_w,
+                                                            const float* __restrict__ nh_b,
+                                                            const float* __restrict__ tbias, int time_on_edge) {
+  constexpr int H = 256;
+  const int lane = threadIdx.x & 63;
+  const int f = lane * 4;
+  const int i = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (i >= n_nodes) return;
+  const int a = rowptr[i], b = rowptr[i + 1];
+  v4f agg = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (b > a) {
+    const int t0 = a >> 5, t1 = (b - 1) >> 5;
+    for (int t = t0; t <= t1; ++t) {
+      const int first = 32 * t;
+      int last = first + 31;
+      last = last < n_edges ? last : n_edges - 1;
+      const float* src;
+      if (a <= first) src = part + ((long long)t * 2 + 0) * H;          // owns the tile's first edge
+      else if (b > last) src = part + ((long long)t * 2 + 1) * H;       // owns the tile's last edge
+      else src = direct + (long long)i * H;                              // strictly inside the tile
+      agg += *reinterpret_cast<const v4f*>(src + f);
+    }
+  }
+  const v4f uh = *reinterpret_cast<const v4f*>(node4 + (long long)i * 4 * H + f);
+  v4f x = uh + agg;
+  constexpr float inv_h = 1.0f / 256.0f;
+  const float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * inv_h;
+  v4f d = x - mean;
+  const float rstd = 1.0f / sqrtf(wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * inv_h + 1e-5f);
+  const v4f gw = *reinterpret_cast<const v4f*>(nh_w + f), gb = *reinterpret_cast<const v4f*>(nh_b + f);
+  const v4f tb = *reinterpret_cast<const v4f*>(tbias + f);
+  float* hp = h + (long long)i * H + f;
+  v4f hv = *reinterpret_cast<const v4f*>(hp);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float y = d[q] * rstd * gw[q] + gb[q];
+    y = y > 0.0f ? y : 0.0f;
+    if (!time_on_edge) y += tb[q];
+    hv[q] += y;
+  }
+  *reinterpret_cast<v4f*>(hp) = hv;
+}
+
+// mode: 1 = bf16 planes, 3 = fp16 planes (DIFUSCO_PREC_BF16X3 / DIFUSCO_PREC_FP16X3)
+hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
+                                   const unsigned short* c_planes, const unsigned short* o_planes,
+                                   long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
+                                   const float* tbias, const float* g_o, const float* b_o, const float* b_out,
+                                   int time_on_edge, float* part, float* direct, hipStream_t stream) {
+  if (n_edges <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)((n_edges + 127) / 128);
+  static bool attr_bf = false, attr_fp = false;
+  if (mode == 1) {
+    if (!attr_bf) {
+      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<FBf16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_TOTAL);
+      if (er != hipSuccess) return er;
+      attr_bf = true;
+    }
+    hipLaunchKernelGGL((edge_layer_fused_kernel<FBf16>), dim3(grid), dim3(256), fused::LDS_TOTAL, stream, e, node4, row,
+                       col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
+                       time_on_edge, part, direct);
+  } else if (mode == 3) {
+    if (!attr_fp) {
+      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<FFp16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_TOTAL);
+      if (er != hipSuccess) return er;
+      attr_fp = true;
+    }
+    hipLaunchKernelGGL((edge_layer_fused_kernel<FFp16>), dim3(grid), dim3(256), fused::LDS_TOTAL, stream, e, node4, row,
+                       col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
+                       time_on_edge, part, direct);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
+                                const float* direct, float* h, const float* nh_w, const float* nh_b,
+                                const float* tbias, int time_on_edge, hipStream_t stream) {
+  if (n_nodes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(node_finalize_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, stream, n_nodes, n_edges,
+                     rowptr, node4, part, direct, h, nh_w, nh_b, tbias, time_on_edge);
+  return hipGetLastError();
+}
+
+}  // namespace difusco

@@ -11,6 +11,15 @@ hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long
                              const float* bias, const float* residual, float* y, long long m, int k, int n_out,
                              long long ldy, hipStream_t stream);
 
+hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
+                                   const unsigned short* c_planes, const unsigned short* o_planes,
+                                   long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
+                                   const float* tbias, const float* g_o, const float* b_o, const float* b_out,
+                                   int time_on_edge, float* part, float* direct, hipStream_t stream);
+hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
+                                const float* direct, float* h, const float* nh_w, const float* nh_b,
+                                const float* tbias, int time_on_edge, hipStream_t stream);
+
 hipError_t launch_time_bias(float t, int H, int n_layers, const float* freqs, const float* w0, const float* b0,
                             const float* w2, const float* b2, const float* wl_base, long long layer_stride,
                             long long wl_w_off, long long wl_b_off, float* tbias, hipStream_t stream);

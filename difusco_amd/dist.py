@@ -57,8 +57,9 @@ class BlobEngineConfig(dict):
         }
 
 
-def engine_from_broadcast(state_dict: Optional[dict], device, src: int = 0, group=None, precision: str = "bf16x6"):
+def engine_from_broadcast(state_dict: Optional[dict], device, src: int = 0, group=None, precision: str = "fp16x3",
+                          fused: bool = True):
     from .engine import DenoiseEngine
     (hidden, n_layers, out_channels), blob = broadcast_weights(state_dict, device, src, group)
     return DenoiseEngine(BlobEngineConfig.make(hidden, n_layers, out_channels), device=device, blob=blob,
-                         precision=precision)
+                         precision=precision, fused=fused)

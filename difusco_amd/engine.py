@@ -16,7 +16,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class DenoiseEngine:
-    def __init__(self, state_dict, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "bf16x6"):
+    def __init__(self, state_dict, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
+                 fused: bool = True):
         """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
         ``blob``: an already packed blob (e.g. received by RCCL broadcast) instead of packing here."""
         self.device = torch.device(device)
@@ -30,6 +31,7 @@ class DenoiseEngine:
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
         self.precision = precision
+        self.fused = fused          # fused edge-layer kernel (H == 256, precision bf16x3 / fp16x3)
         self._ws = None
         self.calls = 0
 
@@ -91,6 +93,8 @@ class DenoiseEngine:
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
         a.stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         a.precision = _lib.PRECISIONS[self.precision]
+        a.no_fusion = 0 if self.fused else 1
+        a.row = _ptr(g.row)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
         self.calls += 1

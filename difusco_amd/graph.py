@@ -24,6 +24,7 @@ class CsrGraph:
     rowptr: torch.Tensor            # int32 [n_nodes+1], device
     col: torch.Tensor               # int32 [n_edges], device
     perm: Optional[torch.Tensor]    # int32 [n_edges] CSR slot -> caller edge id; None = identity
+    row: Optional[torch.Tensor] = None       # int32 [n_edges] centre node of each CSR slot, device
     seg_ptr: Optional[torch.Tensor] = None   # int32 [S+1] device; GroupNorm statistic segments
     n_segments: int = 1
 
@@ -51,7 +52,7 @@ def build_csr(edge_index: torch.Tensor, n_nodes: int, device, seg_rows: Optional
     g = CsrGraph(
         n_nodes=n_nodes, n_edges=int(col.shape[0]),
         rowptr=torch.from_numpy(rowptr).to(device), col=torch.from_numpy(col).to(device),
-        perm=None if ident else torch.from_numpy(perm).to(device))
+        perm=None if ident else torch.from_numpy(perm).to(device), row=torch.from_numpy(_row).to(device))
     if seg_rows is not None and len(seg_rows) > 2:
         g.seg_ptr = torch.from_numpy(np.asarray(seg_rows, dtype=np.int32)).to(device)
         g.n_segments = len(seg_rows) - 1
@@ -65,7 +66,9 @@ def complete_graph_batch(batch: int, n: int, device) -> CsrGraph:
     rowptr = (torch.arange(batch * n + 1, dtype=torch.int64) * n).to(torch.int32)
     col = (torch.arange(n, dtype=torch.int32).repeat(batch * n)
            + torch.arange(batch, dtype=torch.int32).repeat_interleave(n * n) * n)
-    g = CsrGraph(n_nodes=batch * n, n_edges=batch * n * n, rowptr=rowptr.to(device), col=col.to(device), perm=None)
+    row = torch.arange(batch * n, dtype=torch.int32).repeat_interleave(n)
+    g = CsrGraph(n_nodes=batch * n, n_edges=batch * n * n, rowptr=rowptr.to(device), col=col.to(device), perm=None,
+                 row=row.to(device))
     if batch > 1:
         g.seg_ptr = (torch.arange(batch + 1, dtype=torch.int64) * n * n).to(torch.int32).to(device)
         g.n_segments = batch

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 3
+#define DIFUSCO_ABI_VERSION 4
 
 enum {
   DIFUSCO_OK = 0,
@@ -152,7 +152,10 @@ typedef struct difusco_step_args {
   size_t workspace_bytes;
   void* stream;           /* hipStream_t */
   int32_t precision;      /* DIFUSCO_PREC_*: arithmetic of the E-row linears (node rows stay exact fp32) */
-  int32_t reserved0;
+  int32_t no_fusion;      /* 0: use the fused edge-layer kernel when available (hidden == 256 and precision
+                             BF16X3 / FP16X3); 1: always run the unfused kernel sequence (A/B and parity tests) */
+  const int32_t* row;     /* [n_edges] centre node of each CSR slot (device); required for the fused kernel,
+                             may be NULL otherwise */
 } difusco_step_args;
 
 size_t difusco_workspace_bytes(int hidden, int n_layers, int n_nodes, int n_edges, int n_segments);
@@ -182,6 +185,18 @@ int difusco_edge_gate_aggregate(int hidden, int n_nodes, const int32_t* rowptr, 
                                 const float* norm_e_w, const float* norm_e_b,
                                 const float* out_ln_w, const float* out_ln_b,
                                 const float* tbias, int time_on_edge, void* stream);
+
+/* The fused edge pass of one layer + node update (edge_layer.hip), H = 256 only:
+ *   e <- e + W_o SiLU(LN_o(ReLU(LN_e(Ah[j]+Bh[i]+C e)) (+t))) + b_o ;  h_i += ReLU(LN_h(Uh_i + sum gate*Vh_j)) (+t)
+ * planes_c / planes_o: the five 16-bit planes of C / per_layer_out[l][2] (see *_PLANES above);
+ * precision = DIFUSCO_PREC_BF16X3 | DIFUSCO_PREC_FP16X3.  scratch: >= difusco_fused_scratch_bytes(). */
+size_t difusco_fused_scratch_bytes(int n_nodes, int n_edges);
+int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int32_t* rowptr, const int32_t* row,
+                             const int32_t* col, const float* node4, float* e, float* h, const void* planes_c,
+                             const void* planes_o, const float* b_c, const float* norm_h_w, const float* norm_h_b,
+                             const float* norm_e_w, const float* norm_e_b, const float* out_ln_w,
+                             const float* out_ln_b, const float* b_out, const float* tbias, int time_on_edge,
+                             void* scratch, void* stream);
 
 /* Elementwise posteriors on already computed predictions (pl_meta_model.py:102-175). */
 int difusco_categorical_posterior(const float* logits, const float* xt, const float* post,

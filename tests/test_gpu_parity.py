@@ -156,6 +156,62 @@ def test_edge_gate_aggregate(dev, L, H, time_on_edge):
     assert (ce_d.cpu() - act_ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("prec,tol", [("fp16x3", 3e-5), ("bf16x3", 3e-4)])
+@pytest.mark.parametrize("time_on_edge", [1, 0])
+@pytest.mark.parametrize("n,p_edge,seed", [(150, 0.35, 0), (64, 0.9, 1), (300, 0.02, 2)])
+def test_edge_layer_fused(dev, L, prec, tol, time_on_edge, n, p_edge, seed):
+    """The fused edge-layer kernel (chained MFMA + neighbour-sum pieces + node update) against plain
+    fp64/fp32 torch math on a variable-degree graph: degrees above and below the 32-edge tile, an empty
+    row, E not a multiple of 128."""
+    import torch.nn.functional as F
+    from difusco_amd import graph, weights
+    H = 256
+    g = torch.Generator().manual_seed(seed)
+    ei = O.er_mis_instance(n, p_edge, seed=seed)
+    ei = ei[:, ei[0] != 5]                                   # node 5: no edges at all
+    rowptr, col, row, perm, _ = graph.csr_from_coo_host(ei, n)
+    E = col.shape[0]
+    node4 = torch.randn(n, 4 * H, generator=g)
+    e = torch.randn(E, H, generator=g) * 2.0
+    h = torch.randn(n, H, generator=g)
+    Wc = (torch.rand(H, H, generator=g) * 2 - 1) / 16 + torch.arange(H).float()[:, None] * 1e-4
+    Wo = (torch.rand(H, H, generator=g) * 2 - 1) / 16 + torch.arange(H).float()[None, :] * 1e-4
+    bc, bo = torch.randn(H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    prm = [1 + 0.1 * torch.randn(H, generator=g) if i % 2 == 0 else 0.1 * torch.randn(H, generator=g) for i in range(6)]
+    tb = torch.randn(H, generator=g)
+    rowt, colt = torch.from_numpy(row).long(), torch.from_numpy(col).long()
+    Uh, Vh, Ah, Bh = node4[:, :H], node4[:, H:2 * H], node4[:, 2 * H:3 * H], node4[:, 3 * H:]
+    ce = (e.double() @ Wc.double().t()).float() + bc
+    e1 = Ah[colt] + Bh[rowt] + ce
+    agg = O.segment_sum(torch.sigmoid(e1) * Vh[colt], rowt, n)
+    hn = F.relu(F.layer_norm(Uh + agg, (H,), prm[0], prm[1], 1e-5))
+    en = F.relu(F.layer_norm(e1, (H,), prm[2], prm[3], 1e-5))
+    if time_on_edge:
+        en = en + tb
+    else:
+        hn = hn + tb
+    h_ref = h + hn
+    act = F.silu(F.layer_norm(en, (H,), prm[4], prm[5], 1e-5))
+    e_ref = e + (act.double() @ Wo.double().t()).float() + bo
+
+    d = lambda t: t.to(dev).contiguous()
+    e_d, h_d, n4_d = d(e), d(h), d(node4)
+    pc, po = d(weights.split_planes(Wc)), d(weights.split_planes(Wo))
+    bc_d, bo_d, tb_d = d(bc), d(bo), d(tb)
+    prm_d = [d(t) for t in prm]
+    rp_d, row_d, col_d = d(torch.from_numpy(rowptr)), d(torch.from_numpy(row)), d(torch.from_numpy(col))
+    scratch = torch.zeros(L.lib().difusco_fused_scratch_bytes(n, E), dtype=torch.uint8, device=dev)
+    L.check(L.lib().difusco_edge_layer_fused(L.PRECISIONS[prec], n, E, _p(rp_d), _p(row_d), _p(col_d), _p(n4_d), _p(e_d),
+                                             _p(h_d), _p(pc), _p(po), _p(bc_d), _p(prm_d[0]), _p(prm_d[1]), _p(prm_d[2]),
+                                             _p(prm_d[3]), _p(prm_d[4]), _p(prm_d[5]), _p(bo_d), _p(tb_d), time_on_edge,
+                                             _p(scratch), _stream()))
+    torch.cuda.synchronize()
+    err_e = (e_d.cpu() - e_ref).abs().max().item()
+    err_h = (h_d.cpu() - h_ref).abs().max().item()
+    print(f"fused {prec} toe={time_on_edge} n={n} E={E}: e L_inf {err_e:.2e}, h L_inf {err_h:.2e}")
+    assert err_e < tol * 10 and err_h < tol * 10, (err_e, err_h)   # |e| ~ 10: tol is relative to the magnitude
+
+
 def test_posterior_kernels(dev, L, golden_dir):
     from difusco_amd import schedules
     z = np.load(os.path.join(golden_dir, "posteriors.npz"))
@@ -329,7 +385,12 @@ def test_golden_mis(dev, golden_dir):
         assert np.abs(out.cpu().numpy() - z[f"gau{i}_out"]).max() < TOL
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3", "fp16x3"])
+def _prec(name):
+    """'fp16x3' -> fused layer kernel where available; 'fp16x3/unfused' -> kernel sequence."""
+    return dict(precision=name.split("/")[0], fused=not name.endswith("/unfused"))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3", "fp16x3", "bf16x3/unfused", "fp16x3/unfused"])
 @pytest.mark.parametrize("H,Lyr,N,K,G", [(256, 3, 60, 10, 2), (256, 12, 100, 20, 1), (128, 2, 33, 5, 3)])
 def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
     """H=256 / 12 layers (the production width) against the oracle on seeded synthetic inputs,
@@ -343,7 +404,7 @@ def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
     xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
     u = torch.rand(ei.shape[1], generator=g)
     tab = O.CategoricalTables()
-    m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev, precision=prec)
+    m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev, **_prec(prec))
     for (t, tt) in [(1000, 969), (57, 31), (1, 0)]:
         ref_out, ref_logits, ref_prob = O.tsp_categorical_denoise_step(p, tab, pts, xt, t, ei, tt, uniform=u, return_aux=True)
         out, logits, prob = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev),
@@ -368,7 +429,7 @@ def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3", "fp16x3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "bf16x3", "fp16x3", "fp16x3/unfused"])
 def test_oracle_tsp_gaussian_full_width(dev, prec):
     from difusco_amd import TSPModel
     H, Lyr, N, K = 256, 4, 80, 12
@@ -380,7 +441,7 @@ def test_oracle_tsp_gaussian_full_width(dev, prec):
     z = torch.randn(ei.shape[1], generator=g)
     tab = O.GaussianTables()
     for trick, steps in [("ddim", [(1000, 969), (1, 0)]), (None, [(700, 699)])]:
-        m = TSPModel(_args("gaussian", K, trick=trick, H=H, L=Lyr), p, device=dev, precision=prec)
+        m = TSPModel(_args("gaussian", K, trick=trick, H=H, L=Lyr), p, device=dev, **_prec(prec))
         for (t, tt) in steps:
             ref_out, ref_pred = O.tsp_gaussian_denoise_step(p, tab, pts, xt, t, ei, tt, inference_trick=trick, noise=z, return_aux=True)
             out, pred = m.gaussian_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev), target_t=np.array([tt]),
@@ -407,7 +468,8 @@ def test_golden_tsp_sparse_precisions(dev, golden_dir, prec):
         print(f"{prec} golden step {i}: logits L_inf {_check_cat(z, i, out, logits, prob):.3e}")
 
 
-def test_oracle_mis_full_width(dev):
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16x3/unfused", "fp32"])
+def test_oracle_mis_full_width(dev, prec):
     from difusco_amd import MISModel
     H, Lyr, n = 256, 4, 120
     p = O.init_params(H, Lyr, 2, seed=8)
@@ -416,12 +478,14 @@ def test_oracle_mis_full_width(dev):
     xt = (torch.randn(n, generator=g) > 0).float()
     u = torch.rand(n, generator=g)
     tab = O.CategoricalTables()
-    m = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev)
+    m = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev, **_prec(prec))
     for (t, tt) in [(1000, 969), (1, 0)]:
         ref_out, ref_logits, ref_prob = O.mis_categorical_denoise_step(p, tab, xt, t, ei, tt, uniform=u, return_aux=True)
         out, logits, prob = m.categorical_denoise_step(xt.to(dev), np.array([t]), dev, ei.to(dev), target_t=np.array([tt]),
                                                        uniform=u, return_aux=True)
-        assert (logits.cpu() - ref_logits).abs().max().item() < TOL
+        e_log = (logits.cpu() - ref_logits).abs().max().item()
+        print(f"MIS {prec} t={t}: logits L_inf {e_log:.3e}")
+        assert e_log < TOL
         assert (prob.cpu() - ref_prob.reshape(-1)).abs().max().item() < TOL
 
 
