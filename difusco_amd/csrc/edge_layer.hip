@@ -176,20 +176,29 @@ __global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.0f;
 
-  // B operand of GEMM 1, slab 0: k offsets {4hh..4hh+3, 8+4hh..8+4hh+3}
-  v4f b0 = *reinterpret_cast<const v4f*>(erow + 4 * hh);
-  v4f b1 = *reinterpret_cast<const v4f*>(erow + 8 + 4 * hh);
+  // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}].  These are cold HBM reads,
+  // so they run RING slabs ahead of the MFMAs in a register ring (plain loads stay in flight across barriers).
+  constexpr int RING = 4;
+  v4f er[RING][2];
+#pragma unroll
+  for (int d = 0; d < RING; ++d) {
+    er[d][0] = *reinterpret_cast<const v4f*>(erow + 16 * d + 4 * hh);
+    er[d][1] = *reinterpret_cast<const v4f*>(erow + 16 * d + 8 + 4 * hh);
+  }
   __syncthreads();
 
   const int a_off = wslot(l31, hh);   // entry = 32 nb + l31 : (entry >> 3) & 1 == (l31 >> 3) & 1
 
   // ================================ GEMM 1 ==========================================================
+#pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     FUSED_LOAD_STAGE(ks + 1)          // ks == 15 prefetches stage 16 = first stage of GEMM 2
-    const int kn = ks < 15 ? ks + 1 : ks;
-    const v4f n0 = *reinterpret_cast<const v4f*>(erow + 16 * kn + 4 * hh);
-    const v4f n1 = *reinterpret_cast<const v4f*>(erow + 16 * kn + 8 + 4 * hh);
-    const float xs[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    const v4f c0 = er[ks % RING][0], c1 = er[ks % RING][1];
+    if (ks + RING < 16) {
+      er[ks % RING][0] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 4 * hh);
+      er[ks % RING][1] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 8 + 4 * hh);
+    }
+    const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
     frag xh, xl;
     split8<T>(xs, xh, xl);
     const unsigned short* wb = wbuf + (ks & 1) * BUF + a_off;
@@ -203,8 +212,6 @@ __global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
     }
     FUSED_STORE_STAGE(ks + 1)
     __syncthreads();
-    b0 = n0;
-    b1 = n1;
   }
 
   // ================================ epilogue 1 =======================================================

@@ -492,10 +492,15 @@ def test_oracle_mis_full_width(dev, prec):
 # ------------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE.json sizes (too big for the oracle in seconds)
 # ------------------------------------------------------------------------------------------------
-def test_full_size_properties_tsp500(dev):
+@pytest.mark.parametrize("fused", [True, False])
+def test_full_size_properties_tsp500(dev, fused):
     """TSP-500 / K=50 / H=256 / 12 layers, 4 graphs: (1) bitwise determinism, (2) replicas of one graph
-    in a batch with per-graph statistic segments give bitwise identical rows, (3) a batch equals its
-    graphs run alone when the statistics are per graph, (4) outputs are {0,1} and finite."""
+    in a batch with per-graph statistic segments give identical rows, (3) a batch equals its graphs run
+    alone when the statistics are per graph, (4) outputs are {0,1} and finite.  (2)/(3) are bitwise for
+    the unfused kernel sequence; the fused kernel sums the neighbour messages in 32-edge tile pieces whose
+    alignment depends on the graph's offset in the batch (25000 edges per graph is not a multiple of 32),
+    so there the identity holds to fp32 summation-order accuracy."""
+    same = torch.equal if not fused else (lambda x, y: (x - y).abs().max().item() < 2e-5)
     from difusco_amd import TSPModel, _lib
     from difusco_amd.graph import build_csr
     H, Lyr, N, K, G = 256, 12, 500, 50, 4
@@ -508,7 +513,7 @@ def test_full_size_properties_tsp500(dev):
     xt1 = (torch.randn(E1, generator=g) > 0).float()
     u1 = torch.rand(E1, generator=g)
     xt, u = xt1.repeat(G).to(dev), u1.repeat(G)
-    m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev)
+    m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev, fused=fused)
     a, la, pa = m.categorical_denoise_step(pts, xt, np.array([500]), dev, ei, target_t=np.array([450]), uniform=u, return_aux=True)
     b, lb, pb = m.categorical_denoise_step(pts, xt, np.array([500]), dev, ei, target_t=np.array([450]), uniform=u, return_aux=True)
     assert torch.equal(a, b) and torch.equal(la, lb)
@@ -523,11 +528,12 @@ def test_full_size_properties_tsp500(dev):
                                    rand=u, want_pred=True, want_prob=True)
     l_seg = l_seg.reshape(G, E1, 2)
     for k in range(1, G):
-        assert torch.equal(l_seg[0], l_seg[k])
+        assert same(l_seg[0], l_seg[k])
     one, l_one, _ = m.categorical_denoise_step(torch.from_numpy(pts1).to(dev), xt1.to(dev), np.array([500]), dev,
                                                torch.from_numpy(ei1).to(dev), target_t=np.array([450]), uniform=u1, return_aux=True)
-    assert torch.equal(l_one, l_seg[0])
-    assert torch.equal(one, o_seg[:E1])
+    assert same(l_one, l_seg[0])
+    if not fused:
+        assert torch.equal(one, o_seg[:E1])
 
 
 def test_sampling_loop_runs(dev):
