@@ -77,8 +77,8 @@ struct Workspace {
   size_t bytes;
 };
 
-// pieces of the neighbour sum written by the fused edge kernel: 2 per 32-edge tile (4 tiles per workgroup)
-size_t fused_part_floats(int64_t E) { return (size_t)((E + 127) / 128) * 4 * 2 * 256; }
+// pieces of the neighbour sum written by the fused edge kernel: 2 per 32-edge tile (8 tiles per workgroup)
+size_t fused_part_floats(int64_t E) { return (size_t)((E + 255) / 256) * 8 * 2 * 256; }
 
 Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk) {
   Workspace w;
@@ -400,6 +400,11 @@ int difusco_gaussian_posterior(const float* pred, const float* xt, const float* 
     return fail(DIFUSCO_EINVAL, "this step draws random numbers: provide rand or use PHILOX");
   HIP_TRY(difusco::launch_gaussian_posterior(pred, xt, post, rand_mode, rand, seed, offset, xt_out, n, (hipStream_t)stream));
   return DIFUSCO_OK;
+}
+
+int difusco_debug_set(int key, int value) {
+  if (key == 0) { difusco::g_fused_ablate = value; return DIFUSCO_OK; }
+  return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }
 
 int difusco_profile_enable(int on, int max_launches) {

@@ -18,12 +18,13 @@
 //     {0..3, 8..11, 4..7, 12..15}).
 //   * fp32 operands are split into two 16-bit planes (fp16: 22 significand bits, or bf16) and multiplied
 //     with 3 MFMA products (hi*hi, hi*lo, lo*hi), accumulated in fp32 (see linear_split.hip).
-// A workgroup = 4 waves = 128 edges; a wave owns a 32-edge tile end to end.  Weights stream through LDS in
-// 16 KiB stages ([256 rows][16 k] x 2 planes for GEMM 1, [128 rows][32 k] x 2 planes for each output half
-// of GEMM 2), double buffered, one barrier per stage; the 32-byte rows are XOR-swizzled so every 16-lane
-// group of ds_read_b128 hits 16 distinct 16-byte bank slots without padding.  GEMM 2 runs in two halves of
-// 128 output features (64 accumulator registers) so that act planes (128) + accumulators fit 256 VGPRs
-// and two workgroups share a CU: one wave's VALU epilogue overlaps the other's MFMA phase.
+// A workgroup = 8 waves = 256 edges (every weight byte fetched from L2 serves 256 edges: the weight stream
+// through L2 was the first bottleneck of the 4-wave version); a wave owns a 32-edge tile end to end.
+// Weights stream through LDS in 16 KiB stages ([256 rows][16 k] x 2 planes for GEMM 1, [64 rows][64 k] x 2
+// planes for each output quarter of GEMM 2) in a 3-buffer ring, loads two stages ahead of the MFMAs, one
+// barrier per stage; the 32-byte rows are XOR-swizzled so every 16-lane group of ds_read_b128 hits 16
+// distinct 16-byte bank slots without padding.  GEMM 2 runs in four quarters of 64 output features (32
+// accumulator registers) so that act planes (128) + accumulators + staging fit 256 VGPRs (2 waves/SIMD).
 //
 // Neighbour sum.  The gated messages m of a tile are transposed through a wave-private LDS scratch
 // (64 features per round) and summed per centre-node segment by lanes = features.  A segment that is
@@ -86,26 +87,36 @@ __device__ __forceinline__ void split8(const float (&x)[8], typename T::frag& hi
 
 namespace fused {
 constexpr int H = 256;
+constexpr int WAVES = 8;                 // 512 threads: 8 tiles of 32 edges = 256 edges per workgroup
 constexpr int PLANE = 256 * 16;          // 16-bit elements per plane per stage
-constexpr int BUF = 2 * PLANE;           // one stage buffer: 2 planes
+constexpr int BUF = 2 * PLANE;           // one stage buffer: 2 planes = 16 KiB
+constexpr int NBUF = 3;                  // stage ring: loads run two stages ahead of the MFMAs
 constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregation scratch (64 + 4 pad)
-constexpr int LDS_W = 2 * BUF * 2;       // bytes: 2 buffers x 2 planes x 8 KiB           = 32768
+constexpr int LDS_W = NBUF * BUF * 2;    // bytes                                          = 49152
 constexpr int LDS_P = 7 * H * 4;         // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O        =  7168
-constexpr int LDS_S = 4 * 32 * SCR_STRIDE * 4;  // bytes: 4 waves x 32 edges x 68 floats  = 34816
-constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;  // 74752 <= 80 KiB -> two workgroups per CU
+constexpr int LDS_S = WAVES * 32 * SCR_STRIDE * 4;  // bytes: 8 waves x 32 edges x 68 f   = 69632
+constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;    // 125952 (one workgroup per CU)
 enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT };
 }  // namespace fused
 
 // LDS element offset of (entry, half) inside a plane: 32-byte rows, halves swapped on odd 8-row groups
 __device__ __forceinline__ int wslot(int entry, int half) { return entry * 16 + ((half ^ ((entry >> 3) & 1)) << 3); }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
+// sigmoid on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+template <typename T, int ABL>
+__global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
     float* e, const float* __restrict__ node4, const int* __restrict__ row, const int* __restrict__ col, int n_edges,
     const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
     const float* __restrict__ b_c, const float* __restrict__ g_e, const float* __restrict__ b_e,
     const float* __restrict__ tbias, const float* __restrict__ g_o, const float* __restrict__ b_o,
     const float* __restrict__ b_out, int time_on_edge, float* __restrict__ part, float* __restrict__ direct) {
+  // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
+  // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
+  constexpr int ablate = ABL;
   using namespace fused;
   typedef typename T::frag frag;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -115,69 +126,15 @@ __global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x * 4 + wave;
-  const int s_base = tile * 32;
-  const int s_raw = s_base + l31;
+  const int tile = blockIdx.x * WAVES + wave;
+  const int s_raw = tile * 32 + l31;
   const bool valid = s_raw < n_edges;
-  const int s = valid ? s_raw : n_edges - 1;
+  const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
   float* erow = e + (long long)s * H;
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
 
-  // layer parameters -> LDS (thread = feature)
-  prm[P_BC * H + tid] = b_c[tid];
-  prm[P_GE * H + tid] = g_e[tid];
-  prm[P_BE * H + tid] = b_e[tid];
-  prm[P_T * H + tid] = time_on_edge ? tbias[tid] : 0.0f;
-  prm[P_GO * H + tid] = g_o[tid];
-  prm[P_BO * H + tid] = b_o[tid];
-  prm[P_BOUT * H + tid] = b_out[tid];
-
-  // ---- weight stage streaming ---------------------------------------------------------------------
-  // stage t < 16 : GEMM 1, slab t of C, entry = weight row.
-  // stage 16 + u : GEMM 2, output half hf = u >> 3, slabs 2 kk, 2 kk + 1 (kk = u & 7) of W_o,
-  //                entry = ksl * 128 + (row - 128 hf).
-  v4u wr[2][2];
-  auto stage_src = [&](int t, int entry) -> const unsigned short* {
-    if (t < 16) return c_planes + ((long long)t * 256 + entry) * 16;
-    const int u = t - 16, hf = u >> 3, kk = u & 7;
-    return o_planes + ((long long)(2 * kk + (entry >> 7)) * 256 + 128 * hf + (entry & 127)) * 16;
-  };
-#define FUSED_LOAD_STAGE(t)                                                                        \
-  {                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
-      const int c = tid + 256 * i;                                                                 \
-      const unsigned short* src = stage_src((t), c >> 1) + (c & 1) * 8;                            \
-      wr[0][i] = *reinterpret_cast<const v4u*>(src);                                               \
-      wr[1][i] = *reinterpret_cast<const v4u*>(src + plane_stride);                                \
-    }                                                                                              \
-  }
-#define FUSED_STORE_STAGE(t)                                                                       \
-  {                                                                                                \
-    unsigned short* dst = wbuf + ((t) & 1) * BUF;                                                  \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
-      const int c = tid + 256 * i;                                                                 \
-      const int off = wslot(c >> 1, c & 1);                                                        \
-      *reinterpret_cast<v4u*>(dst + off) = wr[0][i];                                               \
-      *reinterpret_cast<v4u*>(dst + PLANE + off) = wr[1][i];                                       \
-    }                                                                                              \
-  }
-
-  FUSED_LOAD_STAGE(0)
-  FUSED_STORE_STAGE(0)
-
-  const int j = col[s];
-  const int i_node = row[s];
-  const float* nj = node4 + (long long)j * 4 * H;       // rows U | V | A | B
-  const float* ni = node4 + (long long)i_node * 4 * H;
-
-  v16f acc1[8];
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.0f;
-
-  // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}].  These are cold HBM reads,
-  // so they run RING slabs ahead of the MFMAs in a register ring (plain loads stay in flight across barriers).
+  // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}].  Cold HBM reads: they run
+  // RING slabs ahead of the MFMAs in a register ring (plain loads stay in flight across barriers).
   constexpr int RING = 4;
   v4f er[RING][2];
 #pragma unroll
@@ -185,14 +142,76 @@ __global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
     er[d][0] = *reinterpret_cast<const v4f*>(erow + 16 * d + 4 * hh);
     er[d][1] = *reinterpret_cast<const v4f*>(erow + 16 * d + 8 + 4 * hh);
   }
+
+  // ---- weight stage streaming ---------------------------------------------------------------------
+  // stage t < 16 : GEMM 1, slab t of C, entry = weight row.
+  // stage 16 + u : GEMM 2, output quarter qt = u >> 2 (64 features), slabs 4 kc .. 4 kc + 3 (kc = u & 3) of W_o,
+  //                entry = ksl * 64 + (row - 64 qt).
+  // One 16-byte chunk per thread per plane.  Stage t lives in LDS buffer t % 3 and travels through
+  // register set t % 2; its global loads are issued two iterations before its MFMAs.
+  auto stage_src = [&](int t, int entry) -> const unsigned short* {
+    if (t < 16) return c_planes + ((long long)t * 256 + entry) * 16;
+    const int u = t - 16, qt = u >> 2, kc = u & 3;
+    return o_planes + ((long long)(4 * kc + (entry >> 6)) * 256 + 64 * qt + (entry & 63)) * 16;
+  };
+  v4u wr0[2], wr1[2];
+  const int st_off = wslot(tid >> 1, tid & 1);
+#define FUSED_LOAD_STAGE(t, R)                                                     \
+  {                                                                                \
+    const unsigned short* src = stage_src((t), tid >> 1) + (tid & 1) * 8;          \
+    R[0] = *reinterpret_cast<const v4u*>(src);                                     \
+    R[1] = *reinterpret_cast<const v4u*>(src + plane_stride);                      \
+  }
+#define FUSED_STORE_STAGE(t, R)                                                    \
+  {                                                                                \
+    unsigned short* dst = wbuf + ((t) % NBUF) * BUF + st_off;                      \
+    *reinterpret_cast<v4u*>(dst) = R[0];                                           \
+    *reinterpret_cast<v4u*>(dst + PLANE) = R[1];                                   \
+  }
+  // iteration t: issue loads of stage t+2, multiply stage t, park stage t+1 in LDS, barrier
+#define FUSED_PIPE_BEGIN(t)                                                        \
+  if ((t) + 2 < 32) {                                                              \
+    if (((t) & 1) == 0) FUSED_LOAD_STAGE((t) + 2, wr0) else FUSED_LOAD_STAGE((t) + 2, wr1)  \
+  }
+#define FUSED_PIPE_END(t)                                                          \
+  if ((t) + 1 < 32) {                                                              \
+    if ((((t) + 1) & 1) == 0) FUSED_STORE_STAGE((t) + 1, wr0) else FUSED_STORE_STAGE((t) + 1, wr1) \
+    __syncthreads();                                                               \
+  }
+
+  FUSED_LOAD_STAGE(0, wr0)
+  FUSED_LOAD_STAGE(1, wr1)
+
+  // layer parameters -> LDS (thread = feature)
+  if (tid < H) {
+    prm[P_BC * H + tid] = b_c[tid];
+    prm[P_GE * H + tid] = g_e[tid];
+    prm[P_BE * H + tid] = b_e[tid];
+    prm[P_T * H + tid] = time_on_edge ? tbias[tid] : 0.0f;
+    prm[P_GO * H + tid] = g_o[tid];
+    prm[P_BO * H + tid] = b_o[tid];
+    prm[P_BOUT * H + tid] = b_out[tid];
+  }
+  const int j = col[s];
+  const int i_node = row[s];
+  const float* nj = node4 + (long long)j * 4 * H;       // rows U | V | A | B
+  const float* ni = node4 + (long long)i_node * 4 * H;
+
+  FUSED_STORE_STAGE(0, wr0)
   __syncthreads();
+
+  v16f acc1[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.0f;
 
   const int a_off = wslot(l31, hh);   // entry = 32 nb + l31 : (entry >> 3) & 1 == (l31 >> 3) & 1
 
   // ================================ GEMM 1 ==========================================================
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
-    FUSED_LOAD_STAGE(ks + 1)          // ks == 15 prefetches stage 16 = first stage of GEMM 2
+    FUSED_PIPE_BEGIN(ks)
     const v4f c0 = er[ks % RING][0], c1 = er[ks % RING][1];
     if (ks + RING < 16) {
       er[ks % RING][0] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 4 * hh);
@@ -201,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
     const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
     frag xh, xl;
     split8<T>(xs, xh, xl);
-    const unsigned short* wb = wbuf + (ks & 1) * BUF + a_off;
+    const unsigned short* wb = wbuf + (ks % NBUF) * BUF + a_off;
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
       const frag wh = *reinterpret_cast<const frag*>(wb + nb * 32 * 16);
@@ -210,69 +229,93 @@ __global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
       acc1[nb] = T::mfma(wh, xl, acc1[nb]);
       acc1[nb] = T::mfma(wh, xh, acc1[nb]);
     }
-    FUSED_STORE_STAGE(ks + 1)
-    __syncthreads();
+    FUSED_PIPE_END(ks)
   }
 
   // ================================ epilogue 1 =======================================================
-  // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3
+  // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3.
+  // Neighbour-table rows are gathered one batch (= 2 quads) ahead of their use.
   float s1 = 0.0f;
   const float vmask = valid ? 1.0f : 0.0f;   // lanes past the last edge contribute nothing to the neighbour sum
-#pragma unroll
-  for (int rnd = 0; rnd < 4; ++rnd) {          // 64 features per round: blocks 2 rnd, 2 rnd + 1
-#pragma unroll
-    for (int nq = 0; nq < 2; ++nq) {
-      const int nb = 2 * rnd + nq;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int fb = 32 * nb + 8 * g + 4 * hh;
-        const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
-        const v4f ah = *reinterpret_cast<const v4f*>(nj + 2 * H + fb);
-        const v4f bh = *reinterpret_cast<const v4f*>(ni + 3 * H + fb);
-        const v4f vh = *reinterpret_cast<const v4f*>(nj + H + fb);
-        v4f m;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float ce = acc1[nb][4 * g + q] + bc[q];
-          const float ev = (ah[q] + bh[q]) + ce;
-          acc1[nb][4 * g + q] = ev;
-          s1 += ev;
-          m[q] = sigmoidf_(ev) * vh[q] * vmask;
-        }
-        *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();   // scratch is wave private: LDS ops of one wave complete in order
-    // segmented column sums: lane = feature 64 rnd + lane, walk the 32 edges of the tile
-    {
-      const int f = 64 * rnd + lane;
-      float accv = 0.0f;
-      int prev = -1;       // centre node of the running segment (wave-uniform)
-      int seg = 0;         // 0: first segment of the tile, 1: later
-#pragma unroll 4
-      for (int k = 0; k < 32; ++k) {
-        const int sk = s_base + k;
-        if (sk >= n_edges) break;                         // uniform
-        const int node = row[sk];                         // uniform scalar load
-        if (k > 0 && node != prev) {
-          // close the running segment: the first one may continue from the previous tile
-          if (seg == 0) part[((long long)tile * 2 + 0) * H + f] = accv;
-          else direct[(long long)prev * H + f] = accv;
-          accv = 0.0f;
-          seg = 1;
-        }
-        prev = node;
-        accv += scr[k * SCR_STRIDE + lane];
-      }
-      // the last segment of the tile may continue into the next tile
-      if (prev >= 0) part[((long long)tile * 2 + (seg == 0 ? 0 : 1)) * H + f] = accv;
-    }
-    __builtin_amdgcn_wave_barrier();
+  // segment structure of the tile: bit k of bnd = edge k starts a new centre node (wave uniform)
+  const int i_prev = __shfl_up(i_node, 1, 64);
+  const unsigned bnd = (unsigned)__ballot(l31 > 0 && i_node != i_prev);
+  const int first_end = bnd ? __builtin_ctz(bnd) : 32;
+  float* part0 = part + ((long long)tile * 2 + 0) * H;
+  float* part1 = part + ((long long)tile * 2 + 1) * H;
+
+  v4f ga[2][2][3];
+#define FUSED_GATHER(b, buf)                                                          \
+  {                                                                                   \
+    _Pragma("unroll") for (int q2 = 0; q2 < 2; ++q2) {                                \
+      const int fb_ = 32 * ((b) >> 1) + 8 * (2 * ((b) & 1) + q2) + 4 * hh;            \
+      if constexpr (!(ablate & 1)) {                                                  \
+        ga[buf][q2][0] = *reinterpret_cast<const v4f*>(nj + 2 * H + fb_);             \
+        ga[buf][q2][1] = *reinterpret_cast<const v4f*>(ni + 3 * H + fb_);             \
+        ga[buf][q2][2] = *reinterpret_cast<const v4f*>(nj + H + fb_);                 \
+      } else {                                                                        \
+        ga[buf][q2][0] = ga[buf][q2][1] = ga[buf][q2][2] = v4f{0.f, 0.f, 0.f, 0.f};   \
+      }                                                                               \
+    }                                                                                 \
   }
+  FUSED_GATHER(0, 0)
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {             // batch b: block nb = b >> 1, quads g = 2 (b & 1) + {0, 1}
+    if (b + 1 < 16) {
+      if (((b + 1) & 1) == 0) FUSED_GATHER(b + 1, 0) else FUSED_GATHER(b + 1, 1)
+    }
+    const int nb = b >> 1, nq = nb & 1;
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      const int g = 2 * (b & 1) + q2;
+      const int fb = 32 * nb + 8 * g + 4 * hh;
+      const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
+      const v4f ah = ga[b & 1][q2][0], bh = ga[b & 1][q2][1], vh = ga[b & 1][q2][2];
+      v4f m;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float ce = acc1[nb][4 * g + q] + bc[q];
+        const float ev = (ah[q] + bh[q]) + ce;
+        acc1[nb][4 * g + q] = ev;
+        s1 += ev;
+        m[q] = fast_sigmoid(ev) * vh[q] * vmask;
+      }
+      *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
+    }
+    if ((b & 3) == 3) {
+      // 64 features (blocks 2 rnd, 2 rnd + 1) of all 32 edges are in the scratch: segmented column sums,
+      // lane = feature 64 rnd + lane.  The first segment of a tile may continue from the previous tile and
+      // the last into the next one (part[tile][0|1]); inner segments are complete (direct[node]).
+      const int rnd = b >> 2;
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (!(ablate & 2)) {
+        const int f = 64 * rnd + lane;
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = scr[k * SCR_STRIDE + lane];
+        float accv = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          if (k > 0 && ((bnd >> k) & 1u)) {                      // wave-uniform branch
+            const int node = __builtin_amdgcn_readlane(i_node, k - 1);
+            float* dst = (k == first_end) ? part0 : direct + (long long)node * H;
+            dst[f] = accv;
+            accv = 0.0f;
+          }
+          accv += v[k];
+        }
+        float* dst = (first_end == 32) ? part0 : part1;
+        dst[f] = accv;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#undef FUSED_GATHER
 
   // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
   constexpr float inv_h = 1.0f / 256.0f;
-  const float mean1 = (s1 + __shfl_xor(s1, 32, 64)) * inv_h;
+  constexpr bool skip_math = (ablate & 4) != 0;
+  const float mean1 = skip_math ? 0.0f : (s1 + __shfl_xor(s1, 32, 64)) * inv_h;
   float q1 = 0.0f;
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
@@ -282,35 +325,37 @@ __global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
       acc1[nb][r] = d;
       q1 += d * d;
     }
-  const float rstd1 = 1.0f / sqrtf((q1 + __shfl_xor(q1, 32, 64)) * inv_h + 1e-5f);
+  const float rstd1 = __builtin_amdgcn_rsqf((q1 + __shfl_xor(q1, 32, 64)) * inv_h + 1e-5f);
   float s2 = 0.0f;
+  if constexpr (!skip_math) {
 #pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
+    for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int fb = 32 * nb + 8 * g + 4 * hh;
-      const v4f ge = *reinterpret_cast<const v4f*>(prm + P_GE * H + fb);
-      const v4f be = *reinterpret_cast<const v4f*>(prm + P_BE * H + fb);
-      const v4f tb = *reinterpret_cast<const v4f*>(prm + P_T * H + fb);
+      for (int g = 0; g < 4; ++g) {
+        const int fb = 32 * nb + 8 * g + 4 * hh;
+        const v4f ge = *reinterpret_cast<const v4f*>(prm + P_GE * H + fb);
+        const v4f be = *reinterpret_cast<const v4f*>(prm + P_BE * H + fb);
+        const v4f tb = *reinterpret_cast<const v4f*>(prm + P_T * H + fb);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float y = acc1[nb][4 * g + q] * rstd1 * ge[q] + be[q];
-        y = (y > 0.0f ? y : 0.0f) + tb[q];
-        acc1[nb][4 * g + q] = y;
-        s2 += y;
+        for (int q = 0; q < 4; ++q) {
+          float y = acc1[nb][4 * g + q] * rstd1 * ge[q] + be[q];
+          y = (y > 0.0f ? y : 0.0f) + tb[q];
+          acc1[nb][4 * g + q] = y;
+          s2 += y;
+        }
       }
-    }
+  }
   const float mean2 = (s2 + __shfl_xor(s2, 32, 64)) * inv_h;
-  float q2 = 0.0f;
+  float q2s = 0.0f;
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float d = acc1[nb][r] - mean2;
       acc1[nb][r] = d;
-      q2 += d * d;
+      q2s += d * d;
     }
-  const float rstd2 = 1.0f / sqrtf((q2 + __shfl_xor(q2, 32, 64)) * inv_h + 1e-5f);
+  const float rstd2 = __builtin_amdgcn_rsqf((q2s + __shfl_xor(q2s, 32, 64)) * inv_h + 1e-5f);
 
   // activation -> 16-bit planes, kept in registers as the B operands of GEMM 2
   frag ah_[8][2], al_[8][2];      // [block nb][register group rg] : slab 2 nb + rg
@@ -328,52 +373,52 @@ __global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float z = acc1[nb][4 * g + q] * rstd2 * go[q] + bo[q];
-          a8[4 * g2 + q] = z * sigmoidf_(z);
+          a8[4 * g2 + q] = skip_math ? z : z * fast_sigmoid(z);
         }
       }
       split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
     }
 
-  // ================================ GEMM 2 (two output halves) =======================================
+  // ================================ GEMM 2 (four output quarters of 64 features) ======================
+  constexpr bool skip_gemm2 = (ablate & 8) != 0;   // (barriers must still be executed by every wave)
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    v16f acc2[4];
+  for (int qt = 0; qt < 4; ++qt) {
+    v16f acc2[2];
 #pragma unroll
-    for (int nbp = 0; nbp < 4; ++nbp)
+    for (int nbp = 0; nbp < 2; ++nbp)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[nbp][r] = 0.0f;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const int t = 16 + hf * 8 + kk;
-      if (t < 31) FUSED_LOAD_STAGE(t + 1)
-      const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
+    for (int kc = 0; kc < 4; ++kc) {
+      const int t = 16 + qt * 4 + kc;
+      FUSED_PIPE_BEGIN(t)
+      const unsigned short* wb = wbuf + (t % NBUF) * BUF + a_off;
+      if constexpr (!skip_gemm2) {
 #pragma unroll
-      for (int ksl = 0; ksl < 2; ++ksl) {
-        const int sl = 2 * kk + ksl;          // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
-        const frag xh = ah_[sl >> 1][sl & 1];
-        const frag xl = al_[sl >> 1][sl & 1];
+        for (int ksl = 0; ksl < 4; ++ksl) {
+          const int sl = 4 * kc + ksl;          // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
+          const frag xh = ah_[sl >> 1][sl & 1];
+          const frag xl = al_[sl >> 1][sl & 1];
 #pragma unroll
-        for (int nbp = 0; nbp < 4; ++nbp) {
-          const int ent = (ksl * 128 + nbp * 32) * 16;   // entry = ksl*128 + 32 nbp + l31
-          const frag wh = *reinterpret_cast<const frag*>(wb + ent);
-          const frag wl = *reinterpret_cast<const frag*>(wb + PLANE + ent);
-          acc2[nbp] = T::mfma(wl, xh, acc2[nbp]);
-          acc2[nbp] = T::mfma(wh, xl, acc2[nbp]);
-          acc2[nbp] = T::mfma(wh, xh, acc2[nbp]);
+          for (int nbp = 0; nbp < 2; ++nbp) {
+            const int ent = (ksl * 64 + nbp * 32) * 16;   // entry = ksl*64 + 32 nbp + l31
+            const frag wh = *reinterpret_cast<const frag*>(wb + ent);
+            const frag wl = *reinterpret_cast<const frag*>(wb + PLANE + ent);
+            acc2[nbp] = T::mfma(wl, xh, acc2[nbp]);
+            acc2[nbp] = T::mfma(wh, xl, acc2[nbp]);
+            acc2[nbp] = T::mfma(wh, xh, acc2[nbp]);
+          }
         }
       }
-      if (t < 31) {
-        FUSED_STORE_STAGE(t + 1)
-        __syncthreads();
-      }
+      FUSED_PIPE_END(t)
     }
-    // e <- e + W_o a + b_o  for the features 128 hf + 32 nbp + 8 g + 4 hh + 0..3 of this lane's edge
-    if (valid) {
+    // e <- e + W_o a + b_o  for the features 64 qt + 32 nbp + 8 g + 4 hh + 0..3 of this lane's edge
+    if (valid && !skip_gemm2) {
 #pragma unroll
-      for (int nbp = 0; nbp < 4; ++nbp)
+      for (int nbp = 0; nbp < 2; ++nbp)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int fo = 128 * hf + 32 * nbp + 8 * g + 4 * hh;
+          const int fo = 64 * qt + 32 * nbp + 8 * g + 4 * hh;
           const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BOUT * H + fo);
           const v4f ein = *reinterpret_cast<const v4f*>(erow + fo);
           v4f v;
@@ -385,6 +430,8 @@ __global__ __launch_bounds__(256, 2) void edge_layer_fused_kernel(
   }
 #undef FUSED_LOAD_STAGE
 #undef FUSED_STORE_STAGE
+#undef FUSED_PIPE_BEGIN
+#undef FUSED_PIPE_END
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -439,6 +486,28 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
   *reinterpret_cast<v4f*>(hp) = hv;
 }
 
+int g_fused_ablate = 0;   // profiling knob (difusco_debug_set), 0 in production
+
+template <typename T, int ABL>
+static hipError_t launch_fused_t(float* e, const float* node4, const int* row, const int* col, int n_edges,
+                                 const unsigned short* c_planes, const unsigned short* o_planes, long long plane_stride,
+                                 const float* b_c, const float* g_e, const float* b_e, const float* tbias,
+                                 const float* g_o, const float* b_o, const float* b_out, int time_on_edge, float* part,
+                                 float* direct, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_TOTAL);
+    if (er != hipSuccess) return er;
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)((n_edges + 255) / 256);
+  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL>), dim3(grid), dim3(512), fused::LDS_TOTAL, stream, e, node4, row, col,
+                     n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, part,
+                     direct);
+  return hipGetLastError();
+}
+
 // mode: 1 = bf16 planes, 3 = fp16 planes (DIFUSCO_PREC_BF16X3 / DIFUSCO_PREC_FP16X3)
 hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
                                    const unsigned short* c_planes, const unsigned short* o_planes,
@@ -446,32 +515,20 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
                                    const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                    int time_on_edge, float* part, float* direct, hipStream_t stream) {
   if (n_edges <= 0) return hipSuccess;
-  const unsigned grid = (unsigned)((n_edges + 127) / 128);
-  static bool attr_bf = false, attr_fp = false;
-  if (mode == 1) {
-    if (!attr_bf) {
-      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<FBf16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_TOTAL);
-      if (er != hipSuccess) return er;
-      attr_bf = true;
-    }
-    hipLaunchKernelGGL((edge_layer_fused_kernel<FBf16>), dim3(grid), dim3(256), fused::LDS_TOTAL, stream, e, node4, row,
-                       col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
-                       time_on_edge, part, direct);
-  } else if (mode == 3) {
-    if (!attr_fp) {
-      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<FFp16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_TOTAL);
-      if (er != hipSuccess) return er;
-      attr_fp = true;
-    }
-    hipLaunchKernelGGL((edge_layer_fused_kernel<FFp16>), dim3(grid), dim3(256), fused::LDS_TOTAL, stream, e, node4, row,
-                       col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
-                       time_on_edge, part, direct);
-  } else {
-    return hipErrorInvalidValue;
+#define FUSED_ARGS e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, \
+                   time_on_edge, part, direct, stream
+  if (mode == 1) return launch_fused_t<FBf16, 0>(FUSED_ARGS);
+  if (mode != 3) return hipErrorInvalidValue;
+  switch (g_fused_ablate) {   // profiling-only variants exist for the fp16 kernel
+    case 0: return launch_fused_t<FFp16, 0>(FUSED_ARGS);
+    case 1: return launch_fused_t<FFp16, 1>(FUSED_ARGS);
+    case 2: return launch_fused_t<FFp16, 2>(FUSED_ARGS);
+    case 4: return launch_fused_t<FFp16, 4>(FUSED_ARGS);
+    case 8: return launch_fused_t<FFp16, 8>(FUSED_ARGS);
+    case 15: return launch_fused_t<FFp16, 15>(FUSED_ARGS);
+    default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
+#undef FUSED_ARGS
 }
 
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,

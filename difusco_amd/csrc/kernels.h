@@ -16,6 +16,7 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
                                    long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                    const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                    int time_on_edge, float* part, float* direct, hipStream_t stream);
+extern int g_fused_ablate;
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
                                 const float* tbias, int time_on_edge, hipStream_t stream);

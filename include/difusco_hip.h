@@ -213,6 +213,10 @@ int difusco_gaussian_posterior(const float* pred, const float* xt, const float* 
  * collect() synchronises, fills ms[c] / launches[c] for c < 5, re-arms, returns brackets read. */
 #define DIFUSCO_PROFILE_CATEGORIES 5
 int difusco_profile_enable(int on, int max_launches);
+/* Profiling knobs, never used in production.  key 0: ablation mask of the fused edge-layer kernel
+ * (bit0 skip neighbour-table gathers, bit1 skip the neighbour sum, bit2 skip LN/activation math,
+ * bit3 skip GEMM 2) - results are WRONG with a non-zero mask; only kernel time is meaningful. */
+int difusco_debug_set(int key, int value);
 int difusco_profile_collect(double* ms, int64_t* launches, int n_categories);
 
 #ifdef __cplusplus

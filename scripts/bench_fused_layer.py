@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the fused edge-layer kernel (+ node finalize) at the bench workload size, with the
+profiling-only ablation masks of difusco_debug_set(0, mask).  GPU only."""
+import ctypes
+import sys
+import os
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from difusco_amd import _lib, graph, synthetic, weights  # noqa: E402
+
+dev = torch.device("cuda:0")
+H, N1, K, G = 256, 1000, 100, 8
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp16x3"
+masks = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 4, 3, 7, 8, 15]
+pts, ei = synthetic.tsp_batch(N1, K, range(G))
+g = graph.build_csr(ei, N1 * G, dev)
+E, N = g.n_edges, g.n_nodes
+gen = torch.Generator().manual_seed(0)
+node4 = torch.randn(N, 4 * H, generator=gen).to(dev)
+e0 = torch.randn(E, H, generator=gen).to(dev)
+h0 = torch.randn(N, H, generator=gen).to(dev)
+Wc = ((torch.rand(H, H, generator=gen) * 2 - 1) / 16)
+Wo = ((torch.rand(H, H, generator=gen) * 2 - 1) / 16)
+pc, po = weights.split_planes(Wc).to(dev), weights.split_planes(Wo).to(dev)
+vec = [torch.randn(H, generator=gen).to(dev) * 0.1 for _ in range(4)] + [(1 + 0.1 * torch.randn(H, generator=gen)).to(dev) for _ in range(3)]
+bc, bo, tb, bh, gh, ge, go = vec[0], vec[1], vec[2], vec[3], vec[4], vec[5], vec[6]
+scratch = torch.zeros(_lib.lib().difusco_fused_scratch_bytes(N, E), dtype=torch.uint8, device=dev)
+L = _lib.lib()
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+
+def run(e, h):
+    _lib.check(L.difusco_edge_layer_fused(_lib.PRECISIONS[prec], N, E, P(g.rowptr), P(g.row), P(g.col), P(node4), P(e), P(h),
+                                          P(pc), P(po), P(bc), P(gh), P(bh), P(ge), P(bh), P(go), P(bh), P(bo), P(tb), 1,
+                                          P(scratch), st))
+
+
+for mask in masks:
+    L.difusco_debug_set(0, mask)
+    e, h = e0.clone(), h0.clone()
+    for _ in range(2):
+        run(e, h)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(10):
+        run(e, h)
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / 10
+    print(f"{prec} ablate={mask:2d}: {ms:.3f} ms per layer  (E={E}, {2*E*H*4/ms/1e6:.0f} GB/s algorithmic, "
+          f"{4*E*H*H*3/ms/1e9:.0f} TF issued)")
+L.difusco_debug_set(0, 0)
