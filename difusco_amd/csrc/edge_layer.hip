@@ -20,9 +20,8 @@
 //     with 3 MFMA products (hi*hi, hi*lo, lo*hi), accumulated in fp32 (see linear_split.hip).
 // A workgroup = 8 waves = 256 edges (every weight byte fetched from L2 serves 256 edges: the weight stream
 // through L2 was the first bottleneck of the 4-wave version); a wave owns a 32-edge tile end to end.
-// Weights stream through LDS in 16 KiB stages ([256 rows][16 k] x 2 planes for GEMM 1, [64 rows][64 k] x 2
-// planes for each output quarter of GEMM 2) in a 3-buffer ring, loads two stages ahead of the MFMAs, one
-// barrier per stage; the 32-byte rows are XOR-swizzled so every 16-lane group of ds_read_b128 hits 16
+// Weights stream through LDS in 32 KiB stages (2 x [256 rows][16 k] x 2 planes for GEMM 1, [64 rows][128 k] x 2
+// planes for each output quarter of GEMM 2), double buffered, one barrier per 48 MFMAs; the 32-byte rows are XOR-swizzled so every 16-lane group of ds_read_b128 hits 16
 // distinct 16-byte bank slots without padding.  GEMM 2 runs in four quarters of 64 output features (32
 // accumulator registers) so that act planes (128) + accumulators + staging fit 256 VGPRs (2 waves/SIMD).
 //
@@ -88,14 +87,15 @@ __device__ __forceinline__ void split8(const float (&x)[8], typename T::frag& hi
 namespace fused {
 constexpr int H = 256;
 constexpr int WAVES = 8;                 // 512 threads: 8 tiles of 32 edges = 256 edges per workgroup
-constexpr int PLANE = 256 * 16;          // 16-bit elements per plane per stage
-constexpr int BUF = 2 * PLANE;           // one stage buffer: 2 planes = 16 KiB
-constexpr int NBUF = 3;                  // stage ring: loads run two stages ahead of the MFMAs
+constexpr int PLANE = 512 * 16;          // 16-bit elements per plane per stage (512 rows of 32 bytes)
+constexpr int BUF = 2 * PLANE;           // one stage buffer: 2 planes = 32 KiB
+constexpr int NBUF = 2;                  // double buffered: stage t+1 is fetched while stage t is multiplied
+constexpr int NSTAGE = 16;               // 8 stages per GEMM
 constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregation scratch (64 + 4 pad)
-constexpr int LDS_W = NBUF * BUF * 2;    // bytes                                          = 49152
+constexpr int LDS_W = NBUF * BUF * 2;    // bytes                                          = 65536
 constexpr int LDS_P = 7 * H * 4;         // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O        =  7168
 constexpr int LDS_S = WAVES * 32 * SCR_STRIDE * 4;  // bytes: 8 waves x 32 edges x 68 f   = 69632
-constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;    // 125952 (one workgroup per CU)
+constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;    // 142336 (one workgroup per CU)
 enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT };
 }  // namespace fused
 
@@ -144,43 +144,48 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   }
 
   // ---- weight stage streaming ---------------------------------------------------------------------
-  // stage t < 16 : GEMM 1, slab t of C, entry = weight row.
-  // stage 16 + u : GEMM 2, output quarter qt = u >> 2 (64 features), slabs 4 kc .. 4 kc + 3 (kc = u & 3) of W_o,
-  //                entry = ksl * 64 + (row - 64 qt).
-  // One 16-byte chunk per thread per plane.  Stage t lives in LDS buffer t % 3 and travels through
-  // register set t % 2; its global loads are issued two iterations before its MFMAs.
+  // A stage is 512 rows of 32 bytes per plane (32 KiB for the two planes):
+  //   stage t < 8 : GEMM 1, slabs 2t, 2t+1 of C;  entry = sub * 256 + weight row  (sub = slab - 2t)
+  //   stage 8 + u : GEMM 2, output quarter qt = u >> 1 (64 features), slabs 8 kc .. 8 kc + 7 of W_o (kc = u & 1);
+  //                 entry = ksl * 64 + (row - 64 qt)
+  // Two 16-byte chunks per thread per plane.  Stage t lives in LDS buffer t & 1; its global loads are issued
+  // at the top of iteration t - 1 and parked in LDS at its end: 48 MFMAs per wave cover the L2 latency, and
+  // there is one barrier per 48 MFMAs.
   auto stage_src = [&](int t, int entry) -> const unsigned short* {
-    if (t < 16) return c_planes + ((long long)t * 256 + entry) * 16;
-    const int u = t - 16, qt = u >> 2, kc = u & 3;
-    return o_planes + ((long long)(4 * kc + (entry >> 6)) * 256 + 64 * qt + (entry & 63)) * 16;
+    if (t < 8) return c_planes + ((long long)(2 * t + (entry >> 8)) * 256 + (entry & 255)) * 16;
+    const int u = t - 8, qt = u >> 1, kc = u & 1;
+    return o_planes + ((long long)(8 * kc + (entry >> 6)) * 256 + 64 * qt + (entry & 63)) * 16;
   };
-  v4u wr0[2], wr1[2];
-  const int st_off = wslot(tid >> 1, tid & 1);
-#define FUSED_LOAD_STAGE(t, R)                                                     \
+  v4u wr[2][2];   // [plane][chunk]
+#define FUSED_LOAD_STAGE(t)                                                        \
   {                                                                                \
-    const unsigned short* src = stage_src((t), tid >> 1) + (tid & 1) * 8;          \
-    R[0] = *reinterpret_cast<const v4u*>(src);                                     \
-    R[1] = *reinterpret_cast<const v4u*>(src + plane_stride);                      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
+      const int c = tid + 512 * i;                                                 \
+      const unsigned short* src = stage_src((t), c >> 1) + (c & 1) * 8;            \
+      wr[0][i] = *reinterpret_cast<const v4u*>(src);                               \
+      wr[1][i] = *reinterpret_cast<const v4u*>(src + plane_stride);                \
+    }                                                                              \
   }
-#define FUSED_STORE_STAGE(t, R)                                                    \
+#define FUSED_STORE_STAGE(t)                                                       \
   {                                                                                \
-    unsigned short* dst = wbuf + ((t) % NBUF) * BUF + st_off;                      \
-    *reinterpret_cast<v4u*>(dst) = R[0];                                           \
-    *reinterpret_cast<v4u*>(dst + PLANE) = R[1];                                   \
+    unsigned short* dst = wbuf + ((t) & 1) * BUF;                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
+      const int c = tid + 512 * i;                                                 \
+      const int off = wslot(c >> 1, c & 1);                                        \
+      *reinterpret_cast<v4u*>(dst + off) = wr[0][i];                               \
+      *reinterpret_cast<v4u*>(dst + PLANE + off) = wr[1][i];                       \
+    }                                                                              \
   }
-  // iteration t: issue loads of stage t+2, multiply stage t, park stage t+1 in LDS, barrier
-#define FUSED_PIPE_BEGIN(t)                                                        \
-  if ((t) + 2 < 32) {                                                              \
-    if (((t) & 1) == 0) FUSED_LOAD_STAGE((t) + 2, wr0) else FUSED_LOAD_STAGE((t) + 2, wr1)  \
-  }
-#define FUSED_PIPE_END(t)                                                          \
-  if ((t) + 1 < 32) {                                                              \
-    if ((((t) + 1) & 1) == 0) FUSED_STORE_STAGE((t) + 1, wr0) else FUSED_STORE_STAGE((t) + 1, wr1) \
-    __syncthreads();                                                               \
+  // iteration t: issue loads of stage t+1, multiply stage t, park stage t+1 in LDS, barrier
+#define FUSED_PIPE_BEGIN(t) \
+  if ((t) + 1 < NSTAGE) FUSED_LOAD_STAGE((t) + 1)
+#define FUSED_PIPE_END(t)        \
+  if ((t) + 1 < NSTAGE) {        \
+    FUSED_STORE_STAGE((t) + 1)   \
+    __syncthreads();             \
   }
 
-  FUSED_LOAD_STAGE(0, wr0)
-  FUSED_LOAD_STAGE(1, wr1)
+  FUSED_LOAD_STAGE(0)
 
   // layer parameters -> LDS (thread = feature)
   if (tid < H) {
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   const float* nj = node4 + (long long)j * 4 * H;       // rows U | V | A | B
   const float* ni = node4 + (long long)i_node * 4 * H;
 
-  FUSED_STORE_STAGE(0, wr0)
+  FUSED_STORE_STAGE(0)
   __syncthreads();
 
   v16f acc1[8];
@@ -210,26 +215,30 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
 
   // ================================ GEMM 1 ==========================================================
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    FUSED_PIPE_BEGIN(ks)
-    const v4f c0 = er[ks % RING][0], c1 = er[ks % RING][1];
-    if (ks + RING < 16) {
-      er[ks % RING][0] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 4 * hh);
-      er[ks % RING][1] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 8 + 4 * hh);
-    }
-    const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-    frag xh, xl;
-    split8<T>(xs, xh, xl);
-    const unsigned short* wb = wbuf + (ks % NBUF) * BUF + a_off;
+  for (int t = 0; t < 8; ++t) {
+    FUSED_PIPE_BEGIN(t)
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const frag wh = *reinterpret_cast<const frag*>(wb + nb * 32 * 16);
-      const frag wl = *reinterpret_cast<const frag*>(wb + PLANE + nb * 32 * 16);
-      acc1[nb] = T::mfma(wl, xh, acc1[nb]);
-      acc1[nb] = T::mfma(wh, xl, acc1[nb]);
-      acc1[nb] = T::mfma(wh, xh, acc1[nb]);
+    for (int sub = 0; sub < 2; ++sub) {
+      const int ks = 2 * t + sub;
+      const v4f c0 = er[ks % RING][0], c1 = er[ks % RING][1];
+      if (ks + RING < 16) {
+        er[ks % RING][0] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 4 * hh);
+        er[ks % RING][1] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 8 + 4 * hh);
+      }
+      const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      frag xh, xl;
+      split8<T>(xs, xh, xl);
+      const unsigned short* wb = wbuf + (t & 1) * BUF + sub * 256 * 16 + a_off;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        const frag wh = *reinterpret_cast<const frag*>(wb + nb * 32 * 16);
+        const frag wl = *reinterpret_cast<const frag*>(wb + PLANE + nb * 32 * 16);
+        acc1[nb] = T::mfma(wl, xh, acc1[nb]);
+        acc1[nb] = T::mfma(wh, xl, acc1[nb]);
+        acc1[nb] = T::mfma(wh, xh, acc1[nb]);
+      }
     }
-    FUSED_PIPE_END(ks)
+    FUSED_PIPE_END(t)
   }
 
   // ================================ epilogue 1 =======================================================
@@ -388,15 +397,23 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
     for (int nbp = 0; nbp < 2; ++nbp)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[nbp][r] = 0.0f;
+    v4f ein[2][4];      // residual rows of this quarter, fetched under the quarter's last 48 MFMAs
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      const int t = 16 + qt * 4 + kc;
+    for (int kc = 0; kc < 2; ++kc) {
+      const int t = 8 + qt * 2 + kc;
       FUSED_PIPE_BEGIN(t)
-      const unsigned short* wb = wbuf + (t % NBUF) * BUF + a_off;
+      if (kc == 1 && !skip_gemm2) {
+#pragma unroll
+        for (int nbp = 0; nbp < 2; ++nbp)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            ein[nbp][g] = *reinterpret_cast<const v4f*>(erow + 64 * qt + 32 * nbp + 8 * g + 4 * hh);
+      }
+      const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
       if constexpr (!skip_gemm2) {
 #pragma unroll
-        for (int ksl = 0; ksl < 4; ++ksl) {
-          const int sl = 4 * kc + ksl;          // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
+        for (int ksl = 0; ksl < 8; ++ksl) {
+          const int sl = 8 * kc + ksl;          // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
           const frag xh = ah_[sl >> 1][sl & 1];
           const frag xl = al_[sl >> 1][sl & 1];
 #pragma unroll
@@ -420,10 +437,9 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
         for (int g = 0; g < 4; ++g) {
           const int fo = 64 * qt + 32 * nbp + 8 * g + 4 * hh;
           const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BOUT * H + fo);
-          const v4f ein = *reinterpret_cast<const v4f*>(erow + fo);
           v4f v;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = ein[q] + (acc2[nbp][4 * g + q] + bo[q]);
+          for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
           *reinterpret_cast<v4f*>(erow + fo) = v;
         }
     }
