@@ -402,6 +402,11 @@ int difusco_gaussian_posterior(const float* pred, const float* xt, const float* 
   return DIFUSCO_OK;
 }
 
+int difusco_debug_set_ptr(int key, void* p) {
+  if (key == 1) { difusco::g_fused_dbg = reinterpret_cast<unsigned long long*>(p); return DIFUSCO_OK; }
+  return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
+}
+
 int difusco_debug_set(int key, int value) {
   if (key == 0) { difusco::g_fused_ablate = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
     const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
     const float* __restrict__ b_c, const float* __restrict__ g_e, const float* __restrict__ b_e,
     const float* __restrict__ tbias, const float* __restrict__ g_o, const float* __restrict__ b_o,
-    const float* __restrict__ b_out, int time_on_edge, float* __restrict__ part, float* __restrict__ direct) {
+    const float* __restrict__ b_out, int time_on_edge, float* __restrict__ part, float* __restrict__ direct,
+    unsigned long long* dbg) {   // dbg: optional phase timestamps (profiling), nullptr in production
   // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
   // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
   constexpr int ablate = ABL;
@@ -132,6 +133,11 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
   float* erow = e + (long long)s * H;
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
+#define FUSED_STAMP(k)                                                                          \
+  if constexpr ((ABL & 16) != 0) {                                                              \
+    if (dbg != nullptr && lane == 0) dbg[((long long)blockIdx.x * WAVES + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  }
+  FUSED_STAMP(0)
 
   // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}].  Cold HBM reads: they run
   // RING slabs ahead of the MFMAs in a register ring (plain loads stay in flight across barriers).
@@ -177,8 +183,13 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
     }                                                                              \
   }
   // iteration t: issue loads of stage t+1, multiply stage t, park stage t+1 in LDS, barrier
-#define FUSED_PIPE_BEGIN(t) \
-  if ((t) + 1 < NSTAGE) FUSED_LOAD_STAGE((t) + 1)
+// (the sched_barrier pins the loads at the top of the stage: the register-pressure-driven scheduler otherwise
+//  sinks them next to their ds_write and the L2 latency is exposed once per stage)
+#define FUSED_PIPE_BEGIN(t)                     \
+  if ((t) + 1 < NSTAGE) {                       \
+    FUSED_LOAD_STAGE((t) + 1)                   \
+    __builtin_amdgcn_sched_barrier(0);          \
+  }
 #define FUSED_PIPE_END(t)        \
   if ((t) + 1 < NSTAGE) {        \
     FUSED_STORE_STAGE((t) + 1)   \
@@ -205,6 +216,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   FUSED_STORE_STAGE(0)
   __syncthreads();
 
+  FUSED_STAMP(1)
   v16f acc1[8];
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
@@ -217,6 +229,8 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     FUSED_PIPE_BEGIN(t)
+    // B operands of the two slabs of this stage
+    frag xh[2], xl[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int ks = 2 * t + sub;
@@ -226,21 +240,33 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
         er[ks % RING][1] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 8 + 4 * hh);
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-      frag xh, xl;
-      split8<T>(xs, xh, xl);
-      const unsigned short* wb = wbuf + (t & 1) * BUF + sub * 256 * 16 + a_off;
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        const frag wh = *reinterpret_cast<const frag*>(wb + nb * 32 * 16);
-        const frag wl = *reinterpret_cast<const frag*>(wb + PLANE + nb * 32 * 16);
-        acc1[nb] = T::mfma(wl, xh, acc1[nb]);
-        acc1[nb] = T::mfma(wh, xl, acc1[nb]);
-        acc1[nb] = T::mfma(wh, xh, acc1[nb]);
-      }
+      split8<T>(xs, xh[sub], xl[sub]);
     }
+    // 16 weight blocks (bi = sub * 8 + nb), A fragments read from LDS two blocks ahead of their MFMAs
+    const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
+    frag fh[3], fl[3];
+#define FUSED_FRAG1(bi, slot)                                                                        \
+  {                                                                                                  \
+    fh[slot] = *reinterpret_cast<const frag*>(wb + ((bi) >> 3) * 256 * 16 + ((bi) & 7) * 32 * 16);   \
+    fl[slot] = *reinterpret_cast<const frag*>(wb + PLANE + ((bi) >> 3) * 256 * 16 + ((bi) & 7) * 32 * 16); \
+  }
+    FUSED_FRAG1(0, 0)
+    FUSED_FRAG1(1, 1)
+#pragma unroll
+    for (int bi = 0; bi < 16; ++bi) {
+      if (bi + 2 < 16) FUSED_FRAG1(bi + 2, (bi + 2) % 3)
+      __builtin_amdgcn_sched_barrier(0);
+      const int nb = bi & 7, sub = bi >> 3;
+      acc1[nb] = T::mfma(fl[bi % 3], xh[sub], acc1[nb]);
+      acc1[nb] = T::mfma(fh[bi % 3], xl[sub], acc1[nb]);
+      acc1[nb] = T::mfma(fh[bi % 3], xh[sub], acc1[nb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef FUSED_FRAG1
     FUSED_PIPE_END(t)
   }
 
+  FUSED_STAMP(2)
   // ================================ epilogue 1 =======================================================
   // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3.
   // Neighbour-table rows are gathered one batch (= 2 quads) ahead of their use.
@@ -320,6 +346,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
     }
   }
 #undef FUSED_GATHER
+  FUSED_STAMP(3)
 
   // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
   constexpr float inv_h = 1.0f / 256.0f;
@@ -388,8 +415,11 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
       split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
     }
 
+  FUSED_STAMP(4)
   // ================================ GEMM 2 (four output quarters of 64 features) ======================
   constexpr bool skip_gemm2 = (ablate & 8) != 0;   // (barriers must still be executed by every wave)
+  constexpr bool skip_out = (ablate & 32) != 0;    // GEMM 2 without residual read / e store
+  constexpr bool skip_mm2 = (ablate & 64) != 0;    // GEMM 2 output path without its MFMAs
 #pragma unroll
   for (int qt = 0; qt < 4; ++qt) {
     v16f acc2[2];
@@ -402,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
     for (int kc = 0; kc < 2; ++kc) {
       const int t = 8 + qt * 2 + kc;
       FUSED_PIPE_BEGIN(t)
-      if (kc == 1 && !skip_gemm2) {
+      if (kc == 1 && !skip_gemm2 && !skip_out) {
 #pragma unroll
         for (int nbp = 0; nbp < 2; ++nbp)
 #pragma unroll
@@ -410,27 +440,37 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
             ein[nbp][g] = *reinterpret_cast<const v4f*>(erow + 64 * qt + 32 * nbp + 8 * g + 4 * hh);
       }
       const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
-      if constexpr (!skip_gemm2) {
+      if constexpr (!skip_gemm2 && !skip_mm2) {
+        // 16 weight blocks (bi = ksl * 2 + nbp), A fragments read from LDS two blocks ahead of their MFMAs
+        frag fh[3], fl[3];
+#define FUSED_FRAG2(bi, slot)                                                                            \
+  {                                                                                                      \
+    fh[slot] = *reinterpret_cast<const frag*>(wb + (((bi) >> 1) * 64 + ((bi) & 1) * 32) * 16);           \
+    fl[slot] = *reinterpret_cast<const frag*>(wb + PLANE + (((bi) >> 1) * 64 + ((bi) & 1) * 32) * 16);   \
+  }
+        FUSED_FRAG2(0, 0)
+        FUSED_FRAG2(1, 1)
 #pragma unroll
-        for (int ksl = 0; ksl < 8; ++ksl) {
+        for (int bi = 0; bi < 16; ++bi) {
+          if (bi + 2 < 16) FUSED_FRAG2(bi + 2, (bi + 2) % 3)
+          __builtin_amdgcn_sched_barrier(0);
+          const int ksl = bi >> 1, nbp = bi & 1;
           const int sl = 8 * kc + ksl;          // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
-          const frag xh = ah_[sl >> 1][sl & 1];
-          const frag xl = al_[sl >> 1][sl & 1];
-#pragma unroll
-          for (int nbp = 0; nbp < 2; ++nbp) {
-            const int ent = (ksl * 64 + nbp * 32) * 16;   // entry = ksl*64 + 32 nbp + l31
-            const frag wh = *reinterpret_cast<const frag*>(wb + ent);
-            const frag wl = *reinterpret_cast<const frag*>(wb + PLANE + ent);
-            acc2[nbp] = T::mfma(wl, xh, acc2[nbp]);
-            acc2[nbp] = T::mfma(wh, xl, acc2[nbp]);
-            acc2[nbp] = T::mfma(wh, xh, acc2[nbp]);
-          }
+          acc2[nbp] = T::mfma(fl[bi % 3], ah_[sl >> 1][sl & 1], acc2[nbp]);
+          acc2[nbp] = T::mfma(fh[bi % 3], al_[sl >> 1][sl & 1], acc2[nbp]);
+          acc2[nbp] = T::mfma(fh[bi % 3], ah_[sl >> 1][sl & 1], acc2[nbp]);
+          __builtin_amdgcn_sched_barrier(0);
         }
+#undef FUSED_FRAG2
       }
       FUSED_PIPE_END(t)
     }
     // e <- e + W_o a + b_o  for the features 64 qt + 32 nbp + 8 g + 4 hh + 0..3 of this lane's edge
-    if (valid && !skip_gemm2) {
+    if constexpr (skip_out) {
+#pragma unroll
+      for (int nbp = 0; nbp < 2; ++nbp) asm volatile("" ::"v"(acc2[nbp]));   // keep the MFMAs alive
+    }
+    if (valid && !skip_gemm2 && !skip_out) {
 #pragma unroll
       for (int nbp = 0; nbp < 2; ++nbp)
 #pragma unroll
@@ -444,6 +484,8 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
         }
     }
   }
+  FUSED_STAMP(5)
+#undef FUSED_STAMP
 #undef FUSED_LOAD_STAGE
 #undef FUSED_STORE_STAGE
 #undef FUSED_PIPE_BEGIN
@@ -503,6 +545,7 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
 }
 
 int g_fused_ablate = 0;   // profiling knob (difusco_debug_set), 0 in production
+unsigned long long* g_fused_dbg = nullptr;   // profiling: device buffer for phase timestamps, [n_tiles][8]
 
 template <typename T, int ABL>
 static hipError_t launch_fused_t(float* e, const float* node4, const int* row, const int* col, int n_edges,
@@ -520,7 +563,7 @@ static hipError_t launch_fused_t(float* e, const float* node4, const int* row, c
   const unsigned grid = (unsigned)((n_edges + 255) / 256);
   hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL>), dim3(grid), dim3(512), fused::LDS_TOTAL, stream, e, node4, row, col,
                      n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, part,
-                     direct);
+                     direct, g_fused_dbg);
   return hipGetLastError();
 }
 
@@ -542,6 +585,10 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     case 4: return launch_fused_t<FFp16, 4>(FUSED_ARGS);
     case 8: return launch_fused_t<FFp16, 8>(FUSED_ARGS);
     case 15: return launch_fused_t<FFp16, 15>(FUSED_ARGS);
+    case 16: return launch_fused_t<FFp16, 16>(FUSED_ARGS);   // production code + phase timestamps
+    case 32: return launch_fused_t<FFp16, 32>(FUSED_ARGS);
+    case 64: return launch_fused_t<FFp16, 64>(FUSED_ARGS);
+    case 7: return launch_fused_t<FFp16, 7>(FUSED_ARGS);
     default: return hipErrorInvalidValue;
   }
 #undef FUSED_ARGS

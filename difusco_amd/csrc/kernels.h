@@ -17,6 +17,7 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
                                    const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                    int time_on_edge, float* part, float* direct, hipStream_t stream);
 extern int g_fused_ablate;
+extern unsigned long long* g_fused_dbg;
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
                                 const float* tbias, int time_on_edge, hipStream_t stream);

@@ -217,6 +217,9 @@ int difusco_profile_enable(int on, int max_launches);
  * (bit0 skip neighbour-table gathers, bit1 skip the neighbour sum, bit2 skip LN/activation math,
  * bit3 skip GEMM 2) - results are WRONG with a non-zero mask; only kernel time is meaningful. */
 int difusco_debug_set(int key, int value);
+/* key 1: device buffer [n_tiles][8] of uint64 receiving s_memtime stamps of the fused kernel's phases
+ * (NULL disables; profiling only). */
+int difusco_debug_set_ptr(int key, void* p);
 int difusco_profile_collect(double* ms, int64_t* launches, int n_categories);
 
 #ifdef __cplusplus

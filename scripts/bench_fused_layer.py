@@ -54,3 +54,26 @@ for mask in masks:
     print(f"{prec} ablate={mask:2d}: {ms:.3f} ms per layer  (E={E}, {2*E*H*4/ms/1e6:.0f} GB/s algorithmic, "
           f"{4*E*H*H*3/ms/1e9:.0f} TF issued)")
 L.difusco_debug_set(0, 0)
+if len(sys.argv) > 3 and sys.argv[3] == 'nostamp':
+    sys.exit(0)
+# phase timestamps (s_memtime, 100 MHz-class constant clock or shader clock - reported as raw ticks and as shares)
+ntile = ((E + 255) // 256) * 8
+dbg = torch.zeros(ntile * 8, dtype=torch.int64, device=dev)
+L.difusco_debug_set_ptr.argtypes = [ctypes.c_int, ctypes.c_void_p]
+L.difusco_debug_set_ptr(1, ctypes.c_void_p(dbg.data_ptr()))
+L.difusco_debug_set(0, 16)
+e, h = e0.clone(), h0.clone()
+run(e, h)
+torch.cuda.synchronize()
+L.difusco_debug_set_ptr(1, None)
+L.difusco_debug_set(0, 0)
+d = dbg.reshape(ntile, 8)[:, :6].cpu().numpy().astype(np.float64)
+d = d[d[:, 0] > 0]
+names = ["prologue", "GEMM1", "gather+agg", "LN+act", "GEMM2"]
+tot = (d[:, 5] - d[:, 0])
+print(f"phase stamps over {d.shape[0]} waves: total {tot.mean():.0f} ticks/wave (min {tot.min():.0f} max {tot.max():.0f})")
+for i, nme in enumerate(names):
+    seg = d[:, i + 1] - d[:, i]
+    print(f"  {nme:12s} {seg.mean():9.0f} ticks  {100 * seg.mean() / tot.mean():5.1f} %")
+span = d[:, 5].max() - d[:, 0].min()
+print(f"  kernel span {span:.0f} ticks; per-CU busy if 1 WG/CU: {tot.mean() * (ntile / 8) / 256:.0f} ticks")
