@@ -36,6 +36,22 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic_bytes(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    gfx950 half-count correction + WRITE_SIZE), as condensed by scripts/summarize_prof.py into
+    profiles/<round>/pmc_traffic.json for the same bench command.  None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    for key, val in table.items():
+        if key in kernel_name:
+            return {"bytes_per_launch": val["fetch_bytes"] + val["write_bytes"], "fetch_bytes": val["fetch_bytes"],
+                    "write_bytes": val["write_bytes"], "source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc)"}
+    return None
+
+
 def cpu_baseline(n_nodes, k, steps, params):
     """The CPU oracle (port of the reference op sequence, incl. V applied on E gathered rows) on a bounded
     sample: ONE graph of the same workload, 1 warm-up + `steps` timed denoise steps.  This leg is the only
@@ -192,6 +208,7 @@ def main():
             else:
                 out["roofline"] = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": None}
+            out["roofline"]["traffic"] = pmc_traffic_bytes(kname)
             out["roofline"].update({"kernel": kname, "avg_launch_ms": avg_s * 1e3, "launches": n_lin,
                                     "algorithmic_flops_per_launch": flops, "mfma_products": n_prod,
                                     "algorithmic_bytes_per_launch": bytes_alg,

@@ -133,10 +133,10 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
   float* erow = e + (long long)s * H;
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
-#define FUSED_STAMP(k)                                                                          \
-  if constexpr ((ABL & 16) != 0) {                                                              \
-    if (dbg != nullptr && lane == 0) dbg[((long long)blockIdx.x * WAVES + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
-  }
+  // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
+  unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define FUSED_STAMP(k) \
+  if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();
   FUSED_STAMP(0)
 
   // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}].  Cold HBM reads: they run
@@ -264,9 +264,11 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
     }
 #undef FUSED_FRAG1
     FUSED_PIPE_END(t)
+    if (t == 0) { FUSED_STAMP(2) }
+    if (t == 3) { FUSED_STAMP(3) }
   }
 
-  FUSED_STAMP(2)
+  FUSED_STAMP(4)
   // ================================ epilogue 1 =======================================================
   // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3.
   // Neighbour-table rows are gathered one batch (= 2 quads) ahead of their use.
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
     }
   }
 #undef FUSED_GATHER
-  FUSED_STAMP(3)
+  FUSED_STAMP(5)
 
   // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
   constexpr float inv_h = 1.0f / 256.0f;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
       split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
     }
 
-  FUSED_STAMP(4)
+  FUSED_STAMP(6)
   // ================================ GEMM 2 (four output quarters of 64 features) ======================
   constexpr bool skip_gemm2 = (ablate & 8) != 0;   // (barriers must still be executed by every wave)
   constexpr bool skip_out = (ablate & 32) != 0;    // GEMM 2 without residual read / e store
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
 #undef FUSED_FRAG2
       }
       FUSED_PIPE_END(t)
+      if (t == 8) { FUSED_STAMP(7) }
     }
     // e <- e + W_o a + b_o  for the features 64 qt + 32 nbp + 8 g + 4 hh + 0..3 of this lane's edge
     if constexpr (skip_out) {
@@ -483,8 +486,15 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
           *reinterpret_cast<v4f*>(erow + fo) = v;
         }
     }
+    if (qt == 0) { FUSED_STAMP(8) }
   }
-  FUSED_STAMP(5)
+  FUSED_STAMP(9)
+  if constexpr ((ABL & 16) != 0) {
+    if (dbg != nullptr && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) dbg[((long long)blockIdx.x * WAVES + wave) * 16 + k] = stamp[k];
+    }
+  }
 #undef FUSED_STAMP
 #undef FUSED_LOAD_STAGE
 #undef FUSED_STORE_STAGE

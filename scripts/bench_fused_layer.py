@@ -58,7 +58,7 @@ if len(sys.argv) > 3 and sys.argv[3] == 'nostamp':
     sys.exit(0)
 # phase timestamps (s_memtime, 100 MHz-class constant clock or shader clock - reported as raw ticks and as shares)
 ntile = ((E + 255) // 256) * 8
-dbg = torch.zeros(ntile * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(ntile * 16, dtype=torch.int64, device=dev)
 L.difusco_debug_set_ptr.argtypes = [ctypes.c_int, ctypes.c_void_p]
 L.difusco_debug_set_ptr(1, ctypes.c_void_p(dbg.data_ptr()))
 L.difusco_debug_set(0, 16)
@@ -67,13 +67,14 @@ run(e, h)
 torch.cuda.synchronize()
 L.difusco_debug_set_ptr(1, None)
 L.difusco_debug_set(0, 0)
-d = dbg.reshape(ntile, 8)[:, :6].cpu().numpy().astype(np.float64)
+d = dbg.reshape(ntile, 16)[:, :10].cpu().numpy().astype(np.float64)
 d = d[d[:, 0] > 0]
-names = ["prologue", "GEMM1", "gather+agg", "LN+act", "GEMM2"]
-tot = (d[:, 5] - d[:, 0])
+names = ["prologue", "G1 stage 0", "G1 stages 1-3", "G1 stages 4-7", "gather+agg", "LN+act", "G2 stage 8", "G2 rest of quarter 0 + out", "G2 quarters 1-3"]
+tot = (d[:, 9] - d[:, 0])
 print(f"phase stamps over {d.shape[0]} waves: total {tot.mean():.0f} ticks/wave (min {tot.min():.0f} max {tot.max():.0f})")
 for i, nme in enumerate(names):
     seg = d[:, i + 1] - d[:, i]
-    print(f"  {nme:12s} {seg.mean():9.0f} ticks  {100 * seg.mean() / tot.mean():5.1f} %")
-span = d[:, 5].max() - d[:, 0].min()
-print(f"  kernel span {span:.0f} ticks; per-CU busy if 1 WG/CU: {tot.mean() * (ntile / 8) / 256:.0f} ticks")
+    print(f"  {nme:28s} {seg.mean():9.0f} ticks  {100 * seg.mean() / tot.mean():5.1f} %   (min {seg.min():.0f} max {seg.max():.0f})")
+# wall-clock concurrency: how many waves are alive on average
+t0, t1 = d[:, 0].min(), d[:, 9].max()
+print(f"  kernel span {t1 - t0:.0f} ticks; sum of wave lifetimes / span = {tot.sum() / (t1 - t0):.0f} waves in flight (2048 = full)")

@@ -36,6 +36,7 @@ if stats:
 else:
     print("no kernel_stats.csv found")
 
+traffic = {}
 for counter, d in (("FETCH_SIZE", f"prof_fetch_{tag}"), ("WRITE_SIZE", f"prof_write_{tag}")):
     f = find(d, "*counter_collection.csv")
     print(f"\n# rocprofv3 --pmc {counter}  (per launch average, bench.py --steps 2 --warmup 1)")
@@ -54,4 +55,10 @@ for counter, d in (("FETCH_SIZE", f"prof_fetch_{tag}"), ("WRITE_SIZE", f"prof_wr
         raw = acc[k] / cnt[k]
         mb = raw * 1024 / 1e6 * (2.0 if counter == "FETCH_SIZE" else 1.0)
         print(f"{k:92s} {cnt[k]:8d} {raw:14.1f} {mb:14.1f}")
+        short_key = k.split("(")[0].replace("void ", "").split("<")[0].strip()
+        traffic.setdefault(short_key, {"fetch_bytes": 0.0, "write_bytes": 0.0})
+        traffic[short_key]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = mb * 1e6
     print("(MB_per_launch = raw * 1024 B" + (" * 2 (gfx950 FETCH_SIZE half-count correction)" if counter == "FETCH_SIZE" else " (uncalibrated)") + ")")
+
+import json
+json.dump(traffic, open(os.path.join(root, f"pmc_traffic_{tag}.json"), "w"), indent=1)
