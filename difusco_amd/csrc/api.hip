@@ -90,13 +90,13 @@ Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk)
   };
   w.h = (float*)take(sizeof(float) * N * H);
   w.node4 = (float*)take(sizeof(float) * N * 4 * H);
-  w.e = (float*)take(sizeof(float) * E * H);
+  w.e = (float*)take(sizeof(float) * (H == 256 ? (E + 255) / 256 * 256 : E) * H);   // fused path: tiles of 256 edges
   w.tmp = (float*)take(sizeof(float) * (E > 2 ? E : 2) * H);
   w.tbias = (float*)take(sizeof(float) * L * H);
   w.table_in = (float*)take(sizeof(float) * 2 * H);
   w.table = (float*)take(sizeof(float) * 2 * H);
   w.stats = (float*)take(sizeof(float) * S * 64);
-  w.partial = (double*)take(sizeof(double) * (size_t)S * nblk * 64);
+  w.partial = (double*)take(sizeof(double) * (size_t)S * (nblk < 8 ? 8 : nblk) * 64);
   w.part = (float*)take(H == 256 ? sizeof(float) * fused_part_floats(E) : 0);
   w.direct = (float*)take(H == 256 ? sizeof(float) * N * H : 0);
   w.bytes = cur;
@@ -245,6 +245,13 @@ int difusco_denoise_step(const difusco_step_args* a) {
     HIP_TRY(call);           \
   }
 
+  // fused edge-layer path: H = 256, 16-bit split planes, one GroupNorm statistic segment; e is then kept in the
+  // tiled layout (kernels.h: edge_tiled_offset) from the embedding to the head
+  const bool fused = H == 256 && !a->no_fusion && E > 0 && a->n_segments == 1 &&
+                     (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
+  if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
+  const int64_t E_pad = (E + 255) / 256 * 256;
+
   // per-layer time bias rows: time_layer_l(time_embed(timestep_embedding(t)))   [L,H]
   PROF(PROF_EMBED, launch_time_bias(a->t, H, L, G(DIFUSCO_W_TIME_FREQS), G(DIFUSCO_W_TIME0_W), G(DIFUSCO_W_TIME0_B),
                                     G(DIFUSCO_W_TIME2_W), G(DIFUSCO_W_TIME2_B), LW(0, 0), lo.layer_stride,
@@ -258,27 +265,34 @@ int difusco_denoise_step(const difusco_step_args* a) {
     PROF(PROF_EMBED, launch_pos_embed(a->points, G(DIFUSCO_W_DIMT_POS), (int)N, H, ws.node4, st))
     PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
                                        H, H, H, st))
+    if (fused)   // pad lanes of the last tiles must read as zero in every later kernel
+      PROF(PROF_EMBED, hipMemsetAsync(ws.e + (E / 32) * 32 * H, 0, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
     if (a->xt_is_binary) {
       PROF(PROF_EMBED, launch_scalar_embed(nullptr, nullptr, G(DIFUSCO_W_DIMT_SCALAR), 2, H, ws.table_in, st))
       PROF(PROF_EMBED, linear_rows(ws.table_in, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.table,
                                    2, H, H, H, st))
-      PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, ws.table, E, H, ws.e, st))
+      if (fused) PROF(PROF_EMBED, launch_table_rows_tiled(a->xt, a->perm, ws.table, E, ws.e, st))
+      else PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, ws.table, E, H, ws.e, st))
     } else {
       PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
-      PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_PLANES),
-                                         G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.e))
+      if (fused) {
+        const unsigned short* pl = reinterpret_cast<const unsigned short*>(G(DIFUSCO_W_EDGE_EMBED_PLANES)) +
+                                   (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0);
+        PROF(PROF_EMBED, linear_rows_split(ws.tmp, pl, (long long)H * H, a->precision, G(DIFUSCO_W_EDGE_EMBED_B), nullptr,
+                                           ws.e, E, H, H, H, st, /*tiled_out=*/1))
+      } else {
+        PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_PLANES),
+                                           G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.e))
+      }
     }
   } else {
     PROF(PROF_EMBED, launch_scalar_embed(a->xt, nullptr, G(DIFUSCO_W_DIMT_SCALAR), N, H, ws.node4, st))
     PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
                                        H, H, H, st))
-    if (E > 0) PROF(PROF_EMBED, hipMemsetAsync(ws.e, 0, sizeof(float) * E * H, st))
+    if (E > 0) PROF(PROF_EMBED, hipMemsetAsync(ws.e, 0, sizeof(float) * (fused ? E_pad : E) * H, st))
   }
 
   // the GNN layers (gnn_encoder.py:425-449)
-  const bool fused = H == 256 && !a->no_fusion && E > 0 &&
-                     (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
-  if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
   const long long split_off = a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0;  // fp16 planes follow bf16
   for (int l = 0; l < L; ++l) {
     PROF(PROF_LINEAR_NODE, linear_rows(ws.h, LW(l, DIFUSCO_WL_NODE4_W), LW(l, DIFUSCO_WL_NODE4_B), nullptr, ws.node4, N,
@@ -309,6 +323,13 @@ int difusco_denoise_step(const difusco_step_args* a) {
   }
 
   // head + posterior (gnn_encoder.py:400-401 / :412-413, pl_tsp_model.py:133-137, pl_meta_model.py:102-175)
+  if (fused && tsp) {
+    PROF(PROF_HEAD, launch_head_tiled(C, ws.e, E, gn_blocks_for(out_rows) < 8 ? 8 : gn_blocks_for(out_rows) / 8 * 8,
+                                      ws.partial, ws.stats, G(DIFUSCO_W_OUT_GN_W), G(DIFUSCO_W_OUT_GN_B),
+                                      G(DIFUSCO_W_OUT_CONV_W), G(DIFUSCO_W_OUT_CONV_B), a->perm, a->xt, a->post,
+                                      a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st))
+    return DIFUSCO_OK;
+  }
   PROF(PROF_HEAD, launch_head(H, C, tsp ? ws.e : ws.h, a->n_segments > 1 ? a->seg_ptr : nullptr, a->n_segments, out_rows,
                               gn_blocks_for(out_rows), ws.partial, ws.stats, G(DIFUSCO_W_OUT_GN_W), G(DIFUSCO_W_OUT_GN_B),
                               G(DIFUSCO_W_OUT_CONV_W), G(DIFUSCO_W_OUT_CONV_B), tsp ? a->perm : nullptr, a->xt, a->post,

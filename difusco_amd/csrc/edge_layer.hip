@@ -131,7 +131,9 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   const int s_raw = tile * 32 + l31;
   const bool valid = s_raw < n_edges;
   const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
-  float* erow = e + (long long)s * H;
+  // e is stored TILED ("MFMA native", see edge_tiled_offset in kernels.h): per 32-edge tile the 1 KiB that one
+  // wave instruction touches is contiguous, so every access below is a fully coalesced 1 KiB transaction
+  float* etile = e + (long long)tile * (32 * H) + lane * 4;   // + slab * 512 + i * 256
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
   // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
   unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -139,14 +141,15 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();
   FUSED_STAMP(0)
 
-  // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}].  Cold HBM reads: they run
+  // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}] = two float4 of the tiled
+  // layout.  Cold HBM reads: they run
   // RING slabs ahead of the MFMAs in a register ring (plain loads stay in flight across barriers).
   constexpr int RING = 4;
   v4f er[RING][2];
 #pragma unroll
   for (int d = 0; d < RING; ++d) {
-    er[d][0] = *reinterpret_cast<const v4f*>(erow + 16 * d + 4 * hh);
-    er[d][1] = *reinterpret_cast<const v4f*>(erow + 16 * d + 8 + 4 * hh);
+    er[d][0] = *reinterpret_cast<const v4f*>(etile + d * 512);
+    er[d][1] = *reinterpret_cast<const v4f*>(etile + d * 512 + 256);
   }
 
   // ---- weight stage streaming ---------------------------------------------------------------------
@@ -236,8 +239,8 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
       const int ks = 2 * t + sub;
       const v4f c0 = er[ks % RING][0], c1 = er[ks % RING][1];
       if (ks + RING < 16) {
-        er[ks % RING][0] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 4 * hh);
-        er[ks % RING][1] = *reinterpret_cast<const v4f*>(erow + 16 * (ks + RING) + 8 + 4 * hh);
+        er[ks % RING][0] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512);
+        er[ks % RING][1] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512 + 256);
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       split8<T>(xs, xh[sub], xl[sub]);
@@ -273,7 +276,6 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3.
   // Neighbour-table rows are gathered one batch (= 2 quads) ahead of their use.
   float s1 = 0.0f;
-  const float vmask = valid ? 1.0f : 0.0f;   // lanes past the last edge contribute nothing to the neighbour sum
   // segment structure of the tile: bit k of bnd = edge k starts a new centre node (wave uniform)
   const int i_prev = __shfl_up(i_node, 1, 64);
   const unsigned bnd = (unsigned)__ballot(l31 > 0 && i_node != i_prev);
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
         const float ev = (ah[q] + bh[q]) + ce;
         acc1[nb][4 * g + q] = ev;
         s1 += ev;
-        m[q] = fast_sigmoid(ev) * vh[q] * vmask;
+        m[q] = valid ? fast_sigmoid(ev) * vh[q] : 0.0f;   // (select, not multiply: pad lanes may hold anything)
       }
       *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
     }
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
         for (int nbp = 0; nbp < 2; ++nbp)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            ein[nbp][g] = *reinterpret_cast<const v4f*>(erow + 64 * qt + 32 * nbp + 8 * g + 4 * hh);
+            ein[nbp][g] = *reinterpret_cast<const v4f*>(etile + (4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256);
       }
       const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
       if constexpr (!skip_gemm2 && !skip_mm2) {
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
           v4f v;
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
-          *reinterpret_cast<v4f*>(erow + fo) = v;
+          *reinterpret_cast<v4f*>(etile + (4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) = v;
         }
     }
     if (qt == 0) { FUSED_STAMP(8) }

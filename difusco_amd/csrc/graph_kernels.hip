@@ -277,24 +277,36 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
   }
 }
 
-// stats[seg][g] = {mean, rstd}; one 64-thread block per segment, fixed summation order.
-__global__ void gn_finalize_kernel(const double* __restrict__ partial, const int* __restrict__ seg_ptr,
-                                   long long total_rows, int nblk, int ch_per_group, float* __restrict__ stats) {
+// stats[seg][g] = {mean, rstd}; one 256-thread block per segment: thread (c, g, w) adds every 4th block
+// partial of moment w of group g, the 4 chains are combined in a fixed order (deterministic).
+// group_stride_blocks: 1 when every block partial holds all 32 groups (row-major kernels); 8 when block b only
+// holds groups 4 (b % 8) .. 4 (b % 8) + 3 (tiled kernel).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, const int* __restrict__ seg_ptr,
+                                                          long long total_rows, int nblk, int ch_per_group,
+                                                          int group_stride_blocks, float* __restrict__ stats) {
+  __shared__ double red[4][64];
   const int seg = blockIdx.x;
-  const int g = threadIdx.x;
-  if (g >= 32) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += partial[((long long)seg * nblk + b) * 64 + g * 2 + 0];
-    q += partial[((long long)seg * nblk + b) * 64 + g * 2 + 1];
+  const int c = threadIdx.x >> 6, gw = threadIdx.x & 63, g = gw >> 1;
+  double acc = 0.0;
+  if (group_stride_blocks == 1) {
+    for (int b = c; b < nblk; b += 4) acc += partial[((long long)seg * nblk + b) * 64 + gw];
+  } else {
+    for (int b = (g >> 2) + 8 * c; b < nblk; b += 32) acc += partial[((long long)seg * nblk + b) * 64 + gw];
   }
-  const long long rows = seg_ptr ? (long long)(seg_ptr[seg + 1] - seg_ptr[seg]) : total_rows;
-  const double cnt = (double)rows * ch_per_group;
-  const double mean = s / cnt;
-  double var = q / cnt - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  stats[(seg * 32 + g) * 2 + 0] = (float)mean;
-  stats[(seg * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+  red[c][gw] = acc;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int gg = threadIdx.x;
+    const double s = ((red[0][2 * gg] + red[1][2 * gg]) + red[2][2 * gg]) + red[3][2 * gg];
+    const double q = ((red[0][2 * gg + 1] + red[1][2 * gg + 1]) + red[2][2 * gg + 1]) + red[3][2 * gg + 1];
+    const long long rows = seg_ptr ? (long long)(seg_ptr[seg + 1] - seg_ptr[seg]) : total_rows;
+    const double cnt = (double)rows * ch_per_group;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    stats[(seg * 32 + gg) * 2 + 0] = (float)mean;
+    stats[(seg * 32 + gg) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+  }
 }
 
 // ---- posterior arithmetic (shared by the fused head and the stand-alone kernels) -------------------
@@ -409,6 +421,107 @@ __global__ void gaussian_posterior_kernel(const float* __restrict__ pred, const 
   xt_out[idx] = gaussian_step(pred[idx], xt[idx], pp, idx);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tiled-layout (edge_tiled_offset, H = 256) variants used by the fused path: every wave instruction moves
+// one contiguous KiB.
+// ------------------------------------------------------------------------------------------------
+// e0 rows from the 2-row embedding table.  Thread = one float4 of the tiled buffer; positions of pad
+// edges (s >= rows) are left untouched (the driver zeroes the tail once per step).
+__global__ __launch_bounds__(256) void table_rows_tiled_kernel(const float* __restrict__ x, const int* __restrict__ perm,
+                                                               const float* __restrict__ table, long long rows,
+                                                               float* __restrict__ out) {
+  const long long p4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
+  const long long tile = p4 >> 11;                                             // 2048 float4 per tile
+  const int r = (int)(p4 & 2047), ks = r >> 7, i = (r >> 6) & 1, lane = r & 63;
+  const long long s = tile * 32 + (lane & 31);
+  if (s >= rows) return;
+  const int f = 16 * ks + 8 * i + 4 * (lane >> 5);
+  const float xv = x[perm ? perm[s] : s];
+  *reinterpret_cast<v4f*>(out + p4 * 4) = *reinterpret_cast<const v4f*>(table + (xv > 0.5f ? 256 : 0) + f);
+}
+
+// GroupNorm partial sums on the tiled buffer: a KiB chunk (tile, c = 2 ks + i) holds 8 channels = ONE group c of
+// 32 edges.  Block b: groups 4 (b % 8) + wave, tiles b / 8, b / 8 + gridDim.x / 8, ...  Pad lanes hold zeros.
+__global__ __launch_bounds__(256) void gn_partial_tiled_kernel(const float* __restrict__ feat, long long n_tiles,
+                                                               double* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = 4 * (blockIdx.x & 7) + wave;
+  double s = 0.0, q = 0.0;
+  for (long long t = blockIdx.x >> 3; t < n_tiles; t += gridDim.x >> 3) {
+    const v4f x = *reinterpret_cast<const v4f*>(feat + t * 8192 + g * 256 + lane * 4);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      s += (double)x[v];
+      q += (double)x[v] * (double)x[v];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    q += __shfl_xor(q, off, 64);
+  }
+  if (lane == 0) {
+    partial[(long long)blockIdx.x * 64 + g * 2 + 0] = s;
+    partial[(long long)blockIdx.x * 64 + g * 2 + 1] = q;
+  }
+}
+
+// head on the tiled buffer: one wavefront per 32-edge tile; lane (l31, hh) accumulates the conv dot products of
+// edge l31 over its half of the channels, one cross-half exchange, then 32 lanes finish 32 edges at once.
+template <int C>
+__global__ __launch_bounds__(256) void head_apply_tiled_kernel(const float* __restrict__ feat, long long rows,
+                                                               long long n_tiles, const float* __restrict__ stats,
+                                                               const float* __restrict__ gn_w, const float* __restrict__ gn_b,
+                                                               const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+                                                               const int* __restrict__ perm, const float* __restrict__ xt,
+                                                               PostParams pp, float* __restrict__ xt_out,
+                                                               float* __restrict__ pred_out, float* __restrict__ prob_out) {
+  __shared__ float st[64];
+  if (threadIdx.x < 64) st[threadIdx.x] = stats[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long t = wave0; t < n_tiles; t += nwaves) {
+    const float* tp = feat + t * 8192 + lane * 4;
+    float dot[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dot[c] = 0.0f;
+#pragma unroll 4
+    for (int ch = 0; ch < 32; ++ch) {                 // chunk ch = 2 ks + i = GroupNorm group
+      const v4f x = *reinterpret_cast<const v4f*>(tp + ch * 256);
+      const int f = 8 * ch + 4 * hh;
+      const float mean = st[2 * ch], rstd = st[2 * ch + 1];
+      const v4f gw = *reinterpret_cast<const v4f*>(gn_w + f), gb = *reinterpret_cast<const v4f*>(gn_b + f);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float y = (x[v] - mean) * rstd * gw[v] + gb[v];
+        y = y > 0.0f ? y : 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) dot[c] += y * conv_w[c * 256 + f + v];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) dot[c] += __shfl_xor(dot[c], 32, 64);
+    const long long s = t * 32 + l31;
+    if (hh == 0 && s < rows) {
+      const long long idx = perm ? perm[s] : s;
+      if constexpr (C == 2) {
+        const float l0 = dot[0] + conv_b[0], l1 = dot[1] + conv_b[1];
+        if (pred_out) {
+          pred_out[idx * 2 + 0] = l0;
+          pred_out[idx * 2 + 1] = l1;
+        }
+        xt_out[idx] = categorical_step(l0, l1, xt[idx], pp, idx, prob_out ? prob_out + idx : nullptr);
+      } else {
+        const float pred = dot[0] + conv_b[0];
+        if (pred_out) pred_out[idx] = pred;
+        xt_out[idx] = gaussian_step(pred, xt[idx], pp, idx);
+      }
+    }
+  }
+}
+
 // ================================================================================================
 // host-side launchers
 // ================================================================================================
@@ -488,8 +601,8 @@ hipError_t launch_head(int H, int C, const float* feat, const int* seg_ptr, int 
   dim3 grid((unsigned)nblk, (unsigned)n_segments);
   DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((gn_partial_kernel<VEC>), grid, dim3(256), 0, stream, feat, seg_ptr,
                                              total_rows, partial))
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segments), dim3(64), 0, stream, partial, seg_ptr, total_rows, nblk, H / 32,
-                     stats);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segments), dim3(256), 0, stream, partial, seg_ptr, total_rows, nblk, H / 32,
+                     1, stats);
   if (C == 2) {
     DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((head_apply_kernel<VEC, 2>), grid, dim3(256), 0, stream, feat, seg_ptr,
                                                total_rows, stats, gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out,
@@ -525,6 +638,43 @@ hipError_t launch_gaussian_posterior(const float* pred, const float* xt, const f
   pp.rand_mode = rand_mode; pp.rand = rand; pp.seed = seed; pp.offset = offset;
   hipLaunchKernelGGL(gaussian_posterior_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pred, xt, pp,
                      xt_out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_table_rows_tiled(const float* x, const int* perm, const float* table, long long rows, float* out,
+                                   hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  const long long n4 = ((rows + 31) / 32) * 2048;     // float4 slots of all tiles that hold at least one edge
+  hipLaunchKernelGGL(table_rows_tiled_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, perm, table, rows, out);
+  return hipGetLastError();
+}
+
+// GroupNorm + conv + posterior on the tiled e buffer (one statistic segment = the whole call).
+// partial must hold nblk*64 doubles, nblk a multiple of 8.
+hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk, double* partial, float* stats,
+                             const float* gn_w, const float* gn_b, const float* conv_w, const float* conv_b,
+                             const int* perm, const float* xt, const float* post, int rand_mode, const float* rand,
+                             unsigned long long seed, unsigned long long offset, float* xt_out, float* pred_out,
+                             float* prob_out, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  if (nblk < 8 || nblk % 8 != 0) return hipErrorInvalidValue;
+  PostParams pp;
+  for (int i = 0; i < 8; ++i) pp.p[i] = post[i];
+  pp.rand_mode = rand_mode; pp.rand = rand; pp.seed = seed; pp.offset = offset;
+  const long long n_tiles = (rows + 31) / 32;
+  hipLaunchKernelGGL(gn_partial_tiled_kernel, dim3(nblk), dim3(256), 0, stream, feat, n_tiles, partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, nblk, 8, 8, stats);
+  long long blocks = (n_tiles + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  if (C == 2) {
+    hipLaunchKernelGGL((head_apply_tiled_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, feat, rows, n_tiles, stats,
+                       gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out, pred_out, prob_out);
+  } else if (C == 1) {
+    hipLaunchKernelGGL((head_apply_tiled_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, stream, feat, rows, n_tiles, stats,
+                       gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out, pred_out, prob_out);
+  } else {
+    return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

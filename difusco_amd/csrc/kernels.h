@@ -4,12 +4,22 @@
 
 namespace difusco {
 
+// Tiled ("MFMA native") layout of an [E, 256] fp32 edge-feature matrix, used by the fused path.
+// Tile = 32 consecutive edges = 8192 floats laid out [slab ks = f/16 (16)][i = (f/8)%2][lane = ((f/4)%2)*32 + s%32 (64)][q = f%4]:
+// the float4 that lane (s%32, hh) of a wavefront feeds to / receives from a 32x32x16 MFMA for slab ks is at
+//   tile*8192 + ks*512 + i*256 + lane*4,
+// so one wave instruction moves one contiguous KiB.  Rows are padded to a multiple of 256 edges; pad lanes hold 0.
+__host__ __device__ inline long long edge_tiled_offset(long long s, int f) {
+  return (s >> 5) * 8192 + (long long)(f >> 4) * 512 + ((f >> 3) & 1) * 256 + ((((f >> 2) & 1) * 32) + (s & 31)) * 4 + (f & 3);
+}
+
 hipError_t linear_rows(const float* x, const float* w, const float* bias, const float* residual, float* y,
                        long long m, int k, int n_out, long long ldy, hipStream_t stream);
 
+// tiled_out != 0 (k == n_out == 256 only): Y is written in the tiled layout above instead of row major
 hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int mode,
                              const float* bias, const float* residual, float* y, long long m, int k, int n_out,
-                             long long ldy, hipStream_t stream);
+                             long long ldy, hipStream_t stream, int tiled_out = 0);
 
 hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
                                    const unsigned short* c_planes, const unsigned short* o_planes,
@@ -30,6 +40,13 @@ hipError_t launch_scalar_embed(const float* x, const int* perm, const float* dim
                                hipStream_t stream);
 hipError_t launch_table_rows(const float* x, const int* perm, const float* table, long long rows, int H, float* out,
                              hipStream_t stream);
+hipError_t launch_table_rows_tiled(const float* x, const int* perm, const float* table, long long rows, float* out,
+                                   hipStream_t stream);
+hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk, double* partial, float* stats,
+                             const float* gn_w, const float* gn_b, const float* conv_w, const float* conv_b,
+                             const int* perm, const float* xt, const float* post, int rand_mode, const float* rand,
+                             unsigned long long seed, unsigned long long offset, float* xt_out, float* pred_out,
+                             float* prob_out, hipStream_t stream);
 hipError_t launch_edge_gate_aggregate(int H, int n_nodes, const int* rowptr, const int* col, const float* node4,
                                       float* ce_act, float* h, const float* nh_w, const float* nh_b, const float* ne_w,
                                       const float* ne_b, const float* ol_w, const float* ol_b, const float* tbias,

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
                                                                     int n_out_total,
                                                                     const float* __restrict__ bias,
                                                                     const float* residual, float* Y, long long M,
-                                                                    long long ldy) {
+                                                                    long long ldy, int tiled_out) {
   constexpr int RB = 128, NB = FB / 32, BK = 16;
   constexpr int RS = 24;                 // LDS row stride in bf16 elements (32 B data + 16 B pad = 48 B)
   constexpr int WV = (FB * 2 + 255) / 256;  // 16-byte chunks per thread per weight plane per slab
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
         v4f v = {acc[nb][4 * g + 0], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
         if (bias != nullptr) v += *reinterpret_cast<const v4f*>(bias + f);
         if (residual != nullptr) v += *reinterpret_cast<const v4f*>(residual + row * ldy + f);
-        *reinterpret_cast<v4f*>(Y + row * ldy + f) = v;
+        if (tiled_out) *reinterpret_cast<v4f*>(Y + edge_tiled_offset(row, f)) = v;   // f % 4 == 0: one aligned float4
+        else *reinterpret_cast<v4f*>(Y + row * ldy + f) = v;
       }
     }
   }
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
 
 template <int K, int FB, int NS, typename T>
 static hipError_t launch_split(const float* x, const unsigned short* wp, long long plane_stride, const float* bias,
-                               const float* residual, float* y, long long m, int n_out, long long ldy, hipStream_t stream) {
+                               const float* residual, float* y, long long m, int n_out, long long ldy, hipStream_t stream,
+                               int tiled_out) {
   constexpr size_t lds = (size_t)NS * (128 + FB) * 24 * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
@@ -199,7 +201,7 @@ static hipError_t launch_split(const float* x, const unsigned short* wp, long lo
   }
   dim3 grid((unsigned)((m + 127) / 128), (unsigned)(n_out / FB));
   hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS, T>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
-                     bias, residual, y, m, ldy);
+                     bias, residual, y, m, ldy, tiled_out);
   return hipGetLastError();
 }
 
@@ -208,14 +210,15 @@ static hipError_t launch_split(const float* x, const unsigned short* wp, long lo
 // 3 = fp16 x 2 planes (3 products).
 hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int mode,
                              const float* bias, const float* residual, float* y, long long m, int k, int n_out,
-                             long long ldy, hipStream_t stream) {
+                             long long ldy, hipStream_t stream, int tiled_out) {
   if (m <= 0) return hipSuccess;
   if (mode < 1 || mode > 3) return hipErrorInvalidValue;
+  if (tiled_out && (k != 256 || n_out != 256 || residual != nullptr)) return hipErrorInvalidValue;
 #define DIFUSCO_SPLIT_CASE(KK, FBB)                                                                                   \
   if (k == KK && n_out % FBB == 0) {                                                                                  \
-    if (mode == 1) return launch_split<KK, FBB, 2, Bf16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream); \
-    if (mode == 2) return launch_split<KK, FBB, 3, Bf16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream); \
-    return launch_split<KK, FBB, 2, Fp16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream);               \
+    if (mode == 1) return launch_split<KK, FBB, 2, Bf16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out); \
+    if (mode == 2) return launch_split<KK, FBB, 3, Bf16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out); \
+    return launch_split<KK, FBB, 2, Fp16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out);    \
   }
   DIFUSCO_SPLIT_CASE(256, 256)
   DIFUSCO_SPLIT_CASE(128, 128)

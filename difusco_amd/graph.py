@@ -73,3 +73,26 @@ def complete_graph_batch(batch: int, n: int, device) -> CsrGraph:
         g.seg_ptr = (torch.arange(batch + 1, dtype=torch.int64) * n * n).to(torch.int32).to(device)
         g.n_segments = batch
     return g
+
+
+def edge_tiled_offsets(n_edges: int) -> torch.Tensor:
+    """Flat offsets [E_pad, 256] (int64) of the tiled edge-feature layout the fused path keeps ``e`` in
+    (``csrc/kernels.h: edge_tiled_offset``): rows padded to a multiple of 256 edges, tile = 32 edges,
+    [slab f/16][(f/8)%2][((f/4)%2)*32 + s%32][f%4].  Test / debugging helper."""
+    e_pad = (n_edges + 255) // 256 * 256
+    s = torch.arange(e_pad, dtype=torch.int64)[:, None]
+    f = torch.arange(256, dtype=torch.int64)[None, :]
+    return (s >> 5) * 8192 + (f >> 4) * 512 + ((f >> 3) & 1) * 256 + ((((f >> 2) & 1) * 32) + (s & 31)) * 4 + (f & 3)
+
+
+def to_tiled(e: torch.Tensor) -> torch.Tensor:
+    """[E, 256] row-major -> flat tiled buffer of E_pad*256 floats (pad rows zero)."""
+    off = edge_tiled_offsets(e.shape[0]).to(e.device)
+    out = torch.zeros(off.shape[0] * 256, dtype=e.dtype, device=e.device)
+    out[off[: e.shape[0]].reshape(-1)] = e.reshape(-1)
+    return out
+
+
+def from_tiled(buf: torch.Tensor, n_edges: int) -> torch.Tensor:
+    off = edge_tiled_offsets(n_edges).to(buf.device)
+    return buf[off[:n_edges].reshape(-1)].reshape(n_edges, 256)

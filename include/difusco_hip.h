@@ -188,6 +188,9 @@ int difusco_edge_gate_aggregate(int hidden, int n_nodes, const int32_t* rowptr, 
 
 /* The fused edge pass of one layer + node update (edge_layer.hip), H = 256 only:
  *   e <- e + W_o SiLU(LN_o(ReLU(LN_e(Ah[j]+Bh[i]+C e)) (+t))) + b_o ;  h_i += ReLU(LN_h(Uh_i + sum gate*Vh_j)) (+t)
+ * e is in the TILED layout of the fused path: rows padded to a multiple of 256 edges (pad = 0), 32-edge
+ * tiles of 8192 floats ordered [f/16][(f/8)%2][((f/4)%2)*32 + s%32][f%4] (csrc/kernels.h edge_tiled_offset,
+ * difusco_amd.graph.to_tiled) - every wavefront access is then one contiguous KiB.
  * planes_c / planes_o: the five 16-bit planes of C / per_layer_out[l][2] (see *_PLANES above);
  * precision = DIFUSCO_PREC_BF16X3 | DIFUSCO_PREC_FP16X3.  scratch: >= difusco_fused_scratch_bytes(). */
 size_t difusco_fused_scratch_bytes(int n_nodes, int n_edges);

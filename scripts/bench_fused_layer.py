@@ -19,7 +19,7 @@ g = graph.build_csr(ei, N1 * G, dev)
 E, N = g.n_edges, g.n_nodes
 gen = torch.Generator().manual_seed(0)
 node4 = torch.randn(N, 4 * H, generator=gen).to(dev)
-e0 = torch.randn(E, H, generator=gen).to(dev)
+e0 = graph.to_tiled(torch.randn(E, H, generator=gen).to(dev))
 h0 = torch.randn(N, H, generator=gen).to(dev)
 Wc = ((torch.rand(H, H, generator=gen) * 2 - 1) / 16)
 Wo = ((torch.rand(H, H, generator=gen) * 2 - 1) / 16)

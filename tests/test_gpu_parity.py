@@ -195,7 +195,7 @@ def test_edge_layer_fused(dev, L, prec, tol, time_on_edge, n, p_edge, seed):
     e_ref = e + (act.double() @ Wo.double().t()).float() + bo
 
     d = lambda t: t.to(dev).contiguous()
-    e_d, h_d, n4_d = d(e), d(h), d(node4)
+    e_d, h_d, n4_d = graph.to_tiled(d(e)), d(h), d(node4)      # the fused kernel keeps e in the tiled layout
     pc, po = d(weights.split_planes(Wc)), d(weights.split_planes(Wo))
     bc_d, bo_d, tb_d = d(bc), d(bo), d(tb)
     prm_d = [d(t) for t in prm]
@@ -206,8 +206,9 @@ def test_edge_layer_fused(dev, L, prec, tol, time_on_edge, n, p_edge, seed):
                                              _p(prm_d[3]), _p(prm_d[4]), _p(prm_d[5]), _p(bo_d), _p(tb_d), time_on_edge,
                                              _p(scratch), _stream()))
     torch.cuda.synchronize()
-    err_e = (e_d.cpu() - e_ref).abs().max().item()
+    err_e = (graph.from_tiled(e_d, E).cpu() - e_ref).abs().max().item()
     err_h = (h_d.cpu() - h_ref).abs().max().item()
+    assert graph.from_tiled(e_d, (E + 255) // 256 * 256)[E:].abs().max().item() == 0.0      # pad lanes stay zero
     print(f"fused {prec} toe={time_on_edge} n={n} E={E}: e L_inf {err_e:.2e}, h L_inf {err_h:.2e}")
     assert err_e < tol * 10 and err_h < tol * 10, (err_e, err_h)   # |e| ~ 10: tol is relative to the magnitude
 
