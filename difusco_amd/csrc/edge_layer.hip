@@ -133,7 +133,10 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
   // e is stored TILED ("MFMA native", see edge_tiled_offset in kernels.h): per 32-edge tile the 1 KiB that one
   // wave instruction touches is contiguous, so every access below is a fully coalesced 1 KiB transaction
-  float* etile = e + (long long)tile * (32 * H) + lane * 4;   // + slab * 512 + i * 256
+  // Addressing is (wave-uniform 64-bit base + compile-time constant) + 32-bit lane offset so that the loads use
+  // the scalar-base form; per-lane 64-bit pointers with large constant offsets cost a VGPR pair per address.
+  float* const etile = e + (long long)tile * (32 * H);   // + slab * 512 + i * 256 + loff
+  const unsigned loff = lane * 4;
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
   // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
   unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   v4f er[RING][2];
 #pragma unroll
   for (int d = 0; d < RING; ++d) {
-    er[d][0] = *reinterpret_cast<const v4f*>(etile + d * 512);
-    er[d][1] = *reinterpret_cast<const v4f*>(etile + d * 512 + 256);
+    er[d][0] = *reinterpret_cast<const v4f*>(etile + d * 512 + loff);
+    er[d][1] = *reinterpret_cast<const v4f*>(etile + (d * 512 + 256) + loff);
   }
 
   // ---- weight stage streaming ---------------------------------------------------------------------
@@ -160,19 +163,28 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   // Two 16-byte chunks per thread per plane.  Stage t lives in LDS buffer t & 1; its global loads are issued
   // at the top of iteration t - 1 and parked in LDS at its end: 48 MFMAs per wave cover the L2 latency, and
   // there is one barrier per 48 MFMAs.
-  auto stage_src = [&](int t, int entry) -> const unsigned short* {
-    if (t < 8) return c_planes + ((long long)(2 * t + (entry >> 8)) * 256 + (entry & 255)) * 16;
+  // source of chunk c (entry = c >> 1, half = c & 1) of stage t = uniform stage base + a per-thread offset that does
+  // not depend on t (one for the GEMM 1 stage shape, one for the GEMM 2 shape)
+  unsigned voff1[2], voff2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 512 * i, entry = c >> 1, half = c & 1;
+    voff1[i] = (entry >> 8) * 4096 + (entry & 255) * 16 + half * 8;
+    voff2[i] = (entry >> 6) * 4096 + (entry & 63) * 16 + half * 8;
+  }
+  auto stage_base = [&](int t) -> const unsigned short* {      // wave uniform
+    if (t < 8) return c_planes + (long long)(2 * t) * 4096;
     const int u = t - 8, qt = u >> 1, kc = u & 1;
-    return o_planes + ((long long)(8 * kc + (entry >> 6)) * 256 + 64 * qt + (entry & 63)) * 16;
+    return o_planes + (long long)(8 * kc) * 4096 + 64 * qt * 16;
   };
   v4u wr[2][2];   // [plane][chunk]
 #define FUSED_LOAD_STAGE(t)                                                        \
   {                                                                                \
+    const unsigned short* sb = stage_base(t);                                      \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
-      const int c = tid + 512 * i;                                                 \
-      const unsigned short* src = stage_src((t), c >> 1) + (c & 1) * 8;            \
-      wr[0][i] = *reinterpret_cast<const v4u*>(src);                               \
-      wr[1][i] = *reinterpret_cast<const v4u*>(src + plane_stride);                \
+      const unsigned vo = (t) < 8 ? voff1[i] : voff2[i];                           \
+      wr[0][i] = *reinterpret_cast<const v4u*>(sb + vo);                           \
+      wr[1][i] = *reinterpret_cast<const v4u*>(sb + plane_stride + vo);            \
     }                                                                              \
   }
 #define FUSED_STORE_STAGE(t)                                                       \
@@ -239,8 +251,8 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
       const int ks = 2 * t + sub;
       const v4f c0 = er[ks % RING][0], c1 = er[ks % RING][1];
       if (ks + RING < 16) {
-        er[ks % RING][0] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512);
-        er[ks % RING][1] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512 + 256);
+        er[ks % RING][0] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512 + loff);
+        er[ks % RING][1] = *reinterpret_cast<const v4f*>(etile + ((ks + RING) * 512 + 256) + loff);
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       split8<T>(xs, xh[sub], xl[sub]);
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
         for (int nbp = 0; nbp < 2; ++nbp)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            ein[nbp][g] = *reinterpret_cast<const v4f*>(etile + (4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256);
+            ein[nbp][g] = *reinterpret_cast<const v4f*>(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff);
       }
       const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
       if constexpr (!skip_gemm2 && !skip_mm2) {
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
           v4f v;
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
-          *reinterpret_cast<v4f*>(etile + (4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) = v;
+          *reinterpret_cast<v4f*>(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff) = v;
         }
     }
     if (qt == 0) { FUSED_STAMP(8) }

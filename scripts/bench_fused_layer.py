@@ -67,7 +67,7 @@ run(e, h)
 torch.cuda.synchronize()
 L.difusco_debug_set_ptr(1, None)
 L.difusco_debug_set(0, 0)
-d = dbg.reshape(ntile, 16)[:, :10].cpu().numpy().astype(np.float64)
+d = dbg.reshape(ntile, 16)[:, :14].cpu().numpy().astype(np.float64)
 d = d[d[:, 0] > 0]
 names = ["prologue", "G1 stage 0", "G1 stages 1-3", "G1 stages 4-7", "gather+agg", "LN+act", "G2 stage 8", "G2 rest of quarter 0 + out", "G2 quarters 1-3"]
 tot = (d[:, 9] - d[:, 0])
@@ -76,5 +76,9 @@ for i, nme in enumerate(names):
     seg = d[:, i + 1] - d[:, i]
     print(f"  {nme:28s} {seg.mean():9.0f} ticks  {100 * seg.mean() / tot.mean():5.1f} %   (min {seg.min():.0f} max {seg.max():.0f})")
 # wall-clock concurrency: how many waves are alive on average
+for a_, b_, nme in [(7, 10, "G2 stage 9 (2nd of q0)"), (10, 8, "output q0 (ein wait + 8 stores)"), (8, 11, "G2 stage 10 (1st of q1)"),
+                    (11, 12, "G2 stage 11 (2nd of q1)"), (12, 13, "output q1"), (13, 9, "quarters 2-3")]:
+    seg = d[:, b_] - d[:, a_]
+    print(f"  {nme:34s} {seg.mean():9.0f} ticks   (min {seg.min():.0f} max {seg.max():.0f})")
 t0, t1 = d[:, 0].min(), d[:, 9].max()
 print(f"  kernel span {t1 - t0:.0f} ticks; sum of wave lifetimes / span = {tot.sum() / (t1 - t0):.0f} waves in flight (2048 = full)")
