@@ -18,10 +18,11 @@
 //     {0..3, 8..11, 4..7, 12..15}).
 //   * fp32 operands are split into two 16-bit planes (fp16: 22 significand bits, or bf16) and multiplied
 //     with 3 MFMA products (hi*hi, hi*lo, lo*hi), accumulated in fp32 (see linear_split.hip).
-// A workgroup = 8 waves = 256 edges (every weight byte fetched from L2 serves 256 edges: the weight stream
-// through L2 was the first bottleneck of the 4-wave version); a wave owns a 32-edge tile end to end.
-// Weights stream through LDS in 32 KiB stages (2 x [256 rows][16 k] x 2 planes for GEMM 1, [64 rows][128 k] x 2
-// planes for each output quarter of GEMM 2), double buffered, one barrier per 48 MFMAs; the 32-byte rows are XOR-swizzled so every 16-lane group of ds_read_b128 hits 16
+// A wave owns a 32-edge tile end to end; a workgroup is NW = 4 waves (two workgroups per CU, whose phases drift
+// apart so that one's MFMA phases overlap the other's VALU / address-heavy epilogue) or NW = 8 (one per CU, half
+// the L2 weight traffic, phases in lock step) - see fused::Geo; 4 measured ~10 % faster.
+// Weights stream through LDS in stages of 64 NW rows of 32 bytes x 2 planes ([256 rows][16 k] slabs for GEMM 1,
+// [64 rows][16 k] sub-slabs of one output quarter for GEMM 2), double buffered, one barrier per stage; the rows are XOR-swizzled so every 16-lane group of ds_read_b128 hits 16
 // distinct 16-byte bank slots without padding.  GEMM 2 runs in four quarters of 64 output features (32
 // accumulator registers) so that act planes (128) + accumulators + staging fit 256 VGPRs (2 waves/SIMD).
 //
@@ -86,17 +87,31 @@ __device__ __forceinline__ void split8(const float (&x)[8], typename T::frag& hi
 
 namespace fused {
 constexpr int H = 256;
-constexpr int WAVES = 8;                 // 512 threads: 8 tiles of 32 edges = 256 edges per workgroup
-constexpr int PLANE = 512 * 16;          // 16-bit elements per plane per stage (512 rows of 32 bytes)
-constexpr int BUF = 2 * PLANE;           // one stage buffer: 2 planes = 32 KiB
-constexpr int NBUF = 2;                  // double buffered: stage t+1 is fetched while stage t is multiplied
-constexpr int NSTAGE = 16;               // 8 stages per GEMM
 constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregation scratch (64 + 4 pad)
-constexpr int LDS_W = NBUF * BUF * 2;    // bytes                                          = 65536
-constexpr int LDS_P = 7 * H * 4;         // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O        =  7168
-constexpr int LDS_S = WAVES * 32 * SCR_STRIDE * 4;  // bytes: 8 waves x 32 edges x 68 f   = 69632
-constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;    // 142336 (one workgroup per CU)
 enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT };
+
+// Workgroup geometry.  NW waves = NW tiles of 32 edges.  A weight stage holds ENT rows of 32 bytes per plane:
+//   NW = 8: 512 rows (32 KiB / stage), 16 stages, ONE workgroup per CU: every weight byte fetched from L2 serves
+//           256 edges, but all 8 waves walk the phases (GEMM 1, epilogue, GEMM 2) in lock step;
+//   NW = 4: 256 rows (16 KiB / stage), 32 stages, TWO workgroups per CU that drift apart, so one workgroup's
+//           MFMA phases overlap the other's VALU / address-unit heavy epilogue (at twice the L2 weight traffic).
+template <int NW>
+struct Geo {
+  static constexpr int WAVES = NW;
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int ENT = 64 * NW;           // entries (32-byte rows) per plane per stage
+  static constexpr int PLANE = ENT * 16;        // 16-bit elements per plane per stage
+  static constexpr int BUF = 2 * PLANE;         // one stage buffer: 2 planes
+  static constexpr int SPS = ENT / 256;         // GEMM 1: slabs per stage (2 | 1)
+  static constexpr int NS1 = 16 / SPS;          // GEMM 1 stages (8 | 16)
+  static constexpr int KPS = ENT / 64;          // GEMM 2: k slabs per stage (8 | 4)
+  static constexpr int SPQ = 16 / KPS;          // GEMM 2: stages per output quarter (2 | 4)
+  static constexpr int NSTAGE = NS1 + 4 * SPQ;  // 16 | 32
+  static constexpr int LDS_W = 2 * BUF * 2;     // bytes, double buffered             65536 | 32768
+  static constexpr int LDS_P = 7 * H * 4;       // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O     7168
+  static constexpr int LDS_S = NW * 32 * SCR_STRIDE * 4;   // bytes                   69632 | 34816
+  static constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;  // 142336 (1 WG/CU) | 74752 (2 WG/CU)
+};
 }  // namespace fused
 
 // LDS element offset of (entry, half) inside a plane: 32-byte rows, halves swapped on odd 8-row groups
@@ -107,8 +122,8 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
-template <typename T, int ABL>
-__global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
+template <typename T, int ABL, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
     float* e, const float* __restrict__ node4, const int* __restrict__ row, const int* __restrict__ col, int n_edges,
     const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
     const float* __restrict__ b_c, const float* __restrict__ g_e, const float* __restrict__ b_e,
@@ -119,6 +134,9 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
   constexpr int ablate = ABL;
   using namespace fused;
+  typedef Geo<NW> G_;
+  constexpr int WAVES = G_::WAVES, PLANE = G_::PLANE, BUF = G_::BUF, NSTAGE = G_::NSTAGE, SPS = G_::SPS, NS1 = G_::NS1,
+                KPS = G_::KPS, SPQ = G_::SPQ, LDS_W = G_::LDS_W, LDS_P = G_::LDS_P;
   typedef typename T::frag frag;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* wbuf = reinterpret_cast<unsigned short*>(smem_raw);
@@ -168,21 +186,21 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   unsigned voff1[2], voff2[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = tid + 512 * i, entry = c >> 1, half = c & 1;
+    const int c = tid + G_::THREADS * i, entry = c >> 1, half = c & 1;
     voff1[i] = (entry >> 8) * 4096 + (entry & 255) * 16 + half * 8;
     voff2[i] = (entry >> 6) * 4096 + (entry & 63) * 16 + half * 8;
   }
   auto stage_base = [&](int t) -> const unsigned short* {      // wave uniform
-    if (t < 8) return c_planes + (long long)(2 * t) * 4096;
-    const int u = t - 8, qt = u >> 1, kc = u & 1;
-    return o_planes + (long long)(8 * kc) * 4096 + 64 * qt * 16;
+    if (t < NS1) return c_planes + (long long)(SPS * t) * 4096;
+    const int u = t - NS1, qt = u / SPQ, kc = u % SPQ;
+    return o_planes + (long long)(KPS * kc) * 4096 + 64 * qt * 16;
   };
   v4u wr[2][2];   // [plane][chunk]
 #define FUSED_LOAD_STAGE(t)                                                        \
   {                                                                                \
     const unsigned short* sb = stage_base(t);                                      \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
-      const unsigned vo = (t) < 8 ? voff1[i] : voff2[i];                           \
+      const unsigned vo = (t) < NS1 ? voff1[i] : voff2[i];                         \
       wr[0][i] = *reinterpret_cast<const v4u*>(sb + vo);                           \
       wr[1][i] = *reinterpret_cast<const v4u*>(sb + plane_stride + vo);            \
     }                                                                              \
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
   {                                                                                \
     unsigned short* dst = wbuf + ((t) & 1) * BUF;                                  \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
-      const int c = tid + 512 * i;                                                 \
+      const int c = tid + G_::THREADS * i;                                         \
       const int off = wslot(c >> 1, c & 1);                                        \
       *reinterpret_cast<v4u*>(dst + off) = wr[0][i];                               \
       *reinterpret_cast<v4u*>(dst + PLANE + off) = wr[1][i];                       \
@@ -242,13 +260,13 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
 
   // ================================ GEMM 1 ==========================================================
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
+  for (int t = 0; t < NS1; ++t) {
     FUSED_PIPE_BEGIN(t)
-    // B operands of the two slabs of this stage
-    frag xh[2], xl[2];
+    // B operands of the slab(s) of this stage
+    frag xh[SPS], xl[SPS];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int ks = 2 * t + sub;
+    for (int sub = 0; sub < SPS; ++sub) {
+      const int ks = SPS * t + sub;
       const v4f c0 = er[ks % RING][0], c1 = er[ks % RING][1];
       if (ks + RING < 16) {
         er[ks % RING][0] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512 + loff);
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       split8<T>(xs, xh[sub], xl[sub]);
     }
-    // 16 weight blocks (bi = sub * 8 + nb), A fragments read from LDS two blocks ahead of their MFMAs
+    // 8 SPS weight blocks (bi = sub * 8 + nb), A fragments read from LDS two blocks ahead of their MFMAs
     const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
     frag fh[3], fl[3];
 #define FUSED_FRAG1(bi, slot)                                                                        \
@@ -268,8 +286,8 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
     FUSED_FRAG1(0, 0)
     FUSED_FRAG1(1, 1)
 #pragma unroll
-    for (int bi = 0; bi < 16; ++bi) {
-      if (bi + 2 < 16) FUSED_FRAG1(bi + 2, (bi + 2) % 3)
+    for (int bi = 0; bi < 8 * SPS; ++bi) {
+      if (bi + 2 < 8 * SPS) FUSED_FRAG1(bi + 2, (bi + 2) % 3)
       __builtin_amdgcn_sched_barrier(0);
       const int nb = bi & 7, sub = bi >> 3;
       acc1[nb] = T::mfma(fl[bi % 3], xh[sub], acc1[nb]);
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
 #undef FUSED_FRAG1
     FUSED_PIPE_END(t)
     if (t == 0) { FUSED_STAMP(2) }
-    if (t == 3) { FUSED_STAMP(3) }
+    if (t == NS1 / 2 - 1) { FUSED_STAMP(3) }
   }
 
   FUSED_STAMP(4)
@@ -445,10 +463,10 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
       for (int r = 0; r < 16; ++r) acc2[nbp][r] = 0.0f;
     v4f ein[2][4];      // residual rows of this quarter, fetched under the quarter's last 48 MFMAs
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-      const int t = 8 + qt * 2 + kc;
+    for (int kc = 0; kc < SPQ; ++kc) {
+      const int t = NS1 + qt * SPQ + kc;
       FUSED_PIPE_BEGIN(t)
-      if (kc == 1 && !skip_gemm2 && !skip_out) {
+      if (kc == SPQ - 1 && !skip_gemm2 && !skip_out) {
 #pragma unroll
         for (int nbp = 0; nbp < 2; ++nbp)
 #pragma unroll
@@ -457,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
       }
       const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
       if constexpr (!skip_gemm2 && !skip_mm2) {
-        // 16 weight blocks (bi = ksl * 2 + nbp), A fragments read from LDS two blocks ahead of their MFMAs
+        // 2 KPS weight blocks (bi = ksl * 2 + nbp), A fragments read from LDS two blocks ahead of their MFMAs
         frag fh[3], fl[3];
 #define FUSED_FRAG2(bi, slot)                                                                            \
   {                                                                                                      \
@@ -467,11 +485,11 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
         FUSED_FRAG2(0, 0)
         FUSED_FRAG2(1, 1)
 #pragma unroll
-        for (int bi = 0; bi < 16; ++bi) {
-          if (bi + 2 < 16) FUSED_FRAG2(bi + 2, (bi + 2) % 3)
+        for (int bi = 0; bi < 2 * KPS; ++bi) {
+          if (bi + 2 < 2 * KPS) FUSED_FRAG2(bi + 2, (bi + 2) % 3)
           __builtin_amdgcn_sched_barrier(0);
           const int ksl = bi >> 1, nbp = bi & 1;
-          const int sl = 8 * kc + ksl;          // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
+          const int sl = KPS * kc + ksl;        // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
           acc2[nbp] = T::mfma(fl[bi % 3], ah_[sl >> 1][sl & 1], acc2[nbp]);
           acc2[nbp] = T::mfma(fh[bi % 3], al_[sl >> 1][sl & 1], acc2[nbp]);
           acc2[nbp] = T::mfma(fh[bi % 3], ah_[sl >> 1][sl & 1], acc2[nbp]);
@@ -480,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void edge_layer_fused_kernel(
 #undef FUSED_FRAG2
       }
       FUSED_PIPE_END(t)
-      if (t == 8) { FUSED_STAMP(7) }
+      if (t == NS1) { FUSED_STAMP(7) }
     }
     // e <- e + W_o a + b_o  for the features 64 qt + 32 nbp + 8 g + 4 hh + 0..3 of this lane's edge
     if constexpr (skip_out) {
@@ -568,10 +586,11 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
   *reinterpret_cast<v4f*>(hp) = hv;
 }
 
+#define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 int g_fused_ablate = 0;   // profiling knob (difusco_debug_set), 0 in production
 unsigned long long* g_fused_dbg = nullptr;   // profiling: device buffer for phase timestamps, [n_tiles][8]
 
-template <typename T, int ABL>
+template <typename T, int ABL, int NW>
 static hipError_t launch_fused_t(float* e, const float* node4, const int* row, const int* col, int n_edges,
                                  const unsigned short* c_planes, const unsigned short* o_planes, long long plane_stride,
                                  const float* b_c, const float* g_e, const float* b_e, const float* tbias,
@@ -579,13 +598,14 @@ static hipError_t launch_fused_t(float* e, const float* node4, const int* row, c
                                  float* direct, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_TOTAL);
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, fused::Geo<NW>::LDS_TOTAL);
     if (er != hipSuccess) return er;
     attr_set = true;
   }
-  const unsigned grid = (unsigned)((n_edges + 255) / 256);
-  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL>), dim3(grid), dim3(512), fused::LDS_TOTAL, stream, e, node4, row, col,
+  const unsigned grid = (unsigned)((n_edges + 32 * NW - 1) / (32 * NW));
+  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW>), dim3(grid), dim3(64 * NW), fused::Geo<NW>::LDS_TOTAL, stream, e,
+                     node4, row, col,
                      n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, part,
                      direct, g_fused_dbg);
   return hipGetLastError();
@@ -600,19 +620,15 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
   if (n_edges <= 0) return hipSuccess;
 #define FUSED_ARGS e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, \
                    time_on_edge, part, direct, stream
-  if (mode == 1) return launch_fused_t<FBf16, 0>(FUSED_ARGS);
+  if (mode == 1) return launch_fused_t<FBf16, 0, FUSED_NW>(FUSED_ARGS);
   if (mode != 3) return hipErrorInvalidValue;
   switch (g_fused_ablate) {   // profiling-only variants exist for the fp16 kernel
-    case 0: return launch_fused_t<FFp16, 0>(FUSED_ARGS);
-    case 1: return launch_fused_t<FFp16, 1>(FUSED_ARGS);
-    case 2: return launch_fused_t<FFp16, 2>(FUSED_ARGS);
-    case 4: return launch_fused_t<FFp16, 4>(FUSED_ARGS);
-    case 8: return launch_fused_t<FFp16, 8>(FUSED_ARGS);
-    case 15: return launch_fused_t<FFp16, 15>(FUSED_ARGS);
-    case 16: return launch_fused_t<FFp16, 16>(FUSED_ARGS);   // production code + phase timestamps
-    case 32: return launch_fused_t<FFp16, 32>(FUSED_ARGS);
-    case 64: return launch_fused_t<FFp16, 64>(FUSED_ARGS);
-    case 7: return launch_fused_t<FFp16, 7>(FUSED_ARGS);
+    case 0: return launch_fused_t<FFp16, 0, FUSED_NW>(FUSED_ARGS);
+    case 8: return launch_fused_t<FFp16, 8, FUSED_NW>(FUSED_ARGS);
+    case 15: return launch_fused_t<FFp16, 15, FUSED_NW>(FUSED_ARGS);
+    case 16: return launch_fused_t<FFp16, 16, FUSED_NW>(FUSED_ARGS);   // production code + phase timestamps
+    case 100: return launch_fused_t<FFp16, 0, 12 - FUSED_NW>(FUSED_ARGS);   // the other workgroup geometry (A/B)
+    case 116: return launch_fused_t<FFp16, 16, 12 - FUSED_NW>(FUSED_ARGS);
     default: return hipErrorInvalidValue;
   }
 #undef FUSED_ARGS

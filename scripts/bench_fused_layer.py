@@ -13,7 +13,7 @@ from difusco_amd import _lib, graph, synthetic, weights  # noqa: E402
 dev = torch.device("cuda:0")
 H, N1, K, G = 256, 1000, 100, 8
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp16x3"
-masks = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 4, 3, 7, 8, 15]
+masks = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 8, 15, 100]
 pts, ei = synthetic.tsp_batch(N1, K, range(G))
 g = graph.build_csr(ei, N1 * G, dev)
 E, N = g.n_edges, g.n_nodes
@@ -54,6 +54,16 @@ for mask in masks:
     print(f"{prec} ablate={mask:2d}: {ms:.3f} ms per layer  (E={E}, {2*E*H*4/ms/1e6:.0f} GB/s algorithmic, "
           f"{4*E*H*H*3/ms/1e9:.0f} TF issued)")
 L.difusco_debug_set(0, 0)
+# the two workgroup geometries must give the same result (same arithmetic, same tile decomposition)
+outs = []
+for mask in (0, 100):
+    L.difusco_debug_set(0, mask)
+    e, h = e0.clone(), h0.clone()
+    run(e, h)
+    torch.cuda.synchronize()
+    outs.append((e, h))
+L.difusco_debug_set(0, 0)
+print("geometry A/B max |diff| e, h:", (outs[0][0] - outs[1][0]).abs().max().item(), (outs[0][1] - outs[1][1]).abs().max().item())
 if len(sys.argv) > 3 and sys.argv[3] == 'nostamp':
     sys.exit(0)
 # phase timestamps (s_memtime, 100 MHz-class constant clock or shader clock - reported as raw ticks and as shares)
@@ -61,7 +71,7 @@ ntile = ((E + 255) // 256) * 8
 dbg = torch.zeros(ntile * 16, dtype=torch.int64, device=dev)
 L.difusco_debug_set_ptr.argtypes = [ctypes.c_int, ctypes.c_void_p]
 L.difusco_debug_set_ptr(1, ctypes.c_void_p(dbg.data_ptr()))
-L.difusco_debug_set(0, 16)
+L.difusco_debug_set(0, int(os.environ.get('STAMP_VARIANT', '16')))
 e, h = e0.clone(), h0.clone()
 run(e, h)
 torch.cuda.synchronize()
