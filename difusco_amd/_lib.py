@@ -5,7 +5,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
@@ -22,7 +22,7 @@ W_LAYER = ["@node4.weight", "@node4.bias", "layers.{l}.C.weight", "layers.{l}.C.
            "time_embed_layers.{l}.1.weight", "time_embed_layers.{l}.1.bias",
            "per_layer_out.{l}.0.weight", "per_layer_out.{l}.0.bias",
            "per_layer_out.{l}.2.weight", "per_layer_out.{l}.2.bias",
-           "@planes:layers.{l}.C.weight", "@planes:per_layer_out.{l}.2.weight"]
+           "@planes:layers.{l}.C.weight", "@planes:per_layer_out.{l}.2.weight", "@planes:@node4.weight"]
 
 
 class StepArgs(ctypes.Structure):

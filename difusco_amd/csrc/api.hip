@@ -65,6 +65,7 @@ Layout make_layout(int H, int L, int C) {
     push(H); push(H);                                 // per_layer_out LN
     push((int64_t)H * H); push(H);                    // per_layer_out linear
     push((int64_t)5 * H * H / 2); push((int64_t)5 * H * H / 2);  // split planes of C and per_layer_out
+    push((int64_t)5 * 4 * H * H / 2);                             // split planes of the node linear
     if (l == 0) lo.layer_stride = cur - layer0;
   }
   lo.total = cur;
@@ -295,8 +296,15 @@ int difusco_denoise_step(const difusco_step_args* a) {
   // the GNN layers (gnn_encoder.py:425-449)
   const long long split_off = a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0;  // fp16 planes follow bf16
   for (int l = 0; l < L; ++l) {
-    PROF(PROF_LINEAR_NODE, linear_rows(ws.h, LW(l, DIFUSCO_WL_NODE4_W), LW(l, DIFUSCO_WL_NODE4_B), nullptr, ws.node4, N,
-                                       H, 4 * H, 4 * H, st))
+    if (a->precision != DIFUSCO_PREC_FP32 && H == 256) {   // node rows on the same split-precision matrix-core path
+      const unsigned short* npl = reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_NODE4_PLANES)) +
+                                  (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * 4 * H * H : 0);
+      PROF(PROF_LINEAR_NODE, linear_rows_split(ws.h, npl, (long long)4 * H * H, a->precision, LW(l, DIFUSCO_WL_NODE4_B),
+                                               nullptr, ws.node4, N, H, 4 * H, 4 * H, st))
+    } else {
+      PROF(PROF_LINEAR_NODE, linear_rows(ws.h, LW(l, DIFUSCO_WL_NODE4_W), LW(l, DIFUSCO_WL_NODE4_B), nullptr, ws.node4,
+                                         N, H, 4 * H, 4 * H, st))
+    }
     if (fused) {
       PROF(PROF_LINEAR_EDGE,
            launch_edge_layer_fused(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,

@@ -215,19 +215,18 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
       *reinterpret_cast<v4u*>(dst + PLANE + off) = wr[1][i];                       \
     }                                                                              \
   }
-  // iteration t: issue loads of stage t+1, multiply stage t, park stage t+1 in LDS, barrier
-// (the sched_barrier pins the loads at the top of the stage: the register-pressure-driven scheduler otherwise
-//  sinks them next to their ds_write and the L2 latency is exposed once per stage)
-#define FUSED_PIPE_BEGIN(t)                     \
-  if ((t) + 1 < NSTAGE) {                       \
-    FUSED_LOAD_STAGE((t) + 1)                   \
-    __builtin_amdgcn_sched_barrier(0);          \
+  // Write-early pipeline.  Iteration t: park stage t+1 in LDS (its loads were issued one whole iteration ago),
+  // issue the loads of stage t+2 (pinned at the top by the sched_barrier: the register-pressure-driven scheduler
+  // otherwise sinks them next to their use and exposes the L2 latency once per stage), multiply stage t, barrier.
+  // The first GEMM 2 stage pair straddles the epilogue: stage NS1+1 is fetched after it, not held across it.
+#define FUSED_PIPE_BEGIN(t)                                         \
+  if ((t) + 1 < NSTAGE) FUSED_STORE_STAGE((t) + 1)                  \
+  if ((t) + 2 < NSTAGE && (t) + 2 != NS1 + 1) {                     \
+    FUSED_LOAD_STAGE((t) + 2)                                       \
+    __builtin_amdgcn_sched_barrier(0);                              \
   }
-#define FUSED_PIPE_END(t)        \
-  if ((t) + 1 < NSTAGE) {        \
-    FUSED_STORE_STAGE((t) + 1)   \
-    __syncthreads();             \
-  }
+#define FUSED_PIPE_END(t) \
+  if ((t) + 1 < NSTAGE) __syncthreads();
 
   FUSED_LOAD_STAGE(0)
 
@@ -247,6 +246,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   const float* ni = node4 + (long long)i_node * 4 * H;
 
   FUSED_STORE_STAGE(0)
+  FUSED_LOAD_STAGE(1)
   __syncthreads();
 
   FUSED_STAMP(1)
@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 
   FUSED_STAMP(6)
   // ================================ GEMM 2 (four output quarters of 64 features) ======================
+  FUSED_LOAD_STAGE(NS1 + 1)
   constexpr bool skip_gemm2 = (ablate & 8) != 0;   // (barriers must still be executed by every wave)
   constexpr bool skip_out = (ablate & 32) != 0;    // GEMM 2 without residual read / e store
   constexpr bool skip_mm2 = (ablate & 64) != 0;    // GEMM 2 output path without its MFMAs

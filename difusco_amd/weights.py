@@ -91,6 +91,8 @@ def pack_state_dict(state) -> torch.Tensor:
                 t = torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0)
             elif name == "@node4.bias":
                 t = torch.cat([state[f"layers.{l}.{m}.bias"] for m in "UVAB"], dim=0)
+            elif name == "@planes:@node4.weight":
+                t = split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0))
             else:
                 t = fetch(name.format(l=l))
             put(base + i, t)

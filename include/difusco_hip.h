@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 4
+#define DIFUSCO_ABI_VERSION 5
 
 enum {
   DIFUSCO_OK = 0,
@@ -75,7 +75,8 @@ enum {                       /* per layer l, index = GLOBAL_COUNT + l*LAYER_COUN
   DIFUSCO_WL_TIME_W, DIFUSCO_WL_TIME_B,      /* time_embed_layers[l].1 : [H,H/2],[H] */
   DIFUSCO_WL_OUT_LN_W, DIFUSCO_WL_OUT_LN_B,  /* per_layer_out[l].0                   */
   DIFUSCO_WL_OUT_W, DIFUSCO_WL_OUT_B,        /* per_layer_out[l].2 : [H,H],[H]       */
-  DIFUSCO_WL_C_PLANES, DIFUSCO_WL_OUT_PLANES, /* bf16 split planes of C / per_layer_out[l].2 */
+  DIFUSCO_WL_C_PLANES, DIFUSCO_WL_OUT_PLANES, /* split planes of C / per_layer_out[l].2 */
+  DIFUSCO_WL_NODE4_PLANES,                    /* split planes of the [4H,H] node linear (U|V|A|B) */
   DIFUSCO_WL_COUNT
 };
 /* "*_PLANES" entries: the [H,H] weight w decomposed on the host into five 16-bit planes
