@@ -222,18 +222,29 @@ def main():
                                     "hbm_GBs_algorithmic": hbm_gbs})
             n_g = max(prof["launches"][2], 1)
             g_s = prof["ms"][2] / n_g * 1e-3
-            gate_bytes = 2.0 * E_local * H * 4                  # read C e, write act (node tables are L2/MALL traffic)
-            out["kernels"] = {
-                "edge_linear": {"ms_total": prof["ms"][0], "launches": prof["launches"][0]},
-                "node_linear": {"ms_total": prof["ms"][1], "launches": prof["launches"][1]},
-                "edge_gate_aggregate": {"ms_total": prof["ms"][2], "launches": prof["launches"][2],
-                                        "achieved_GBs": gate_bytes / g_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
-                                        "frac": gate_bytes / g_s / 1e9 / PEAK_HBM_GBS, "bound": "hbm",
-                                        "algorithmic_bytes_per_launch": gate_bytes},
+            if fused:
+                out["kernels"] = {
+                    "edge_layer_fused": {"ms_total": prof["ms"][0], "launches": prof["launches"][0],
+                                         "hbm_GBs_algorithmic": hbm_gbs, "hbm_frac_of_8TBs": hbm_gbs / PEAK_HBM_GBS,
+                                         "mfma_TFLOPs_issued": mfma_tf, "mfma_frac": mfma_tf / mfma_peak},
+                    "node_linear": {"ms_total": prof["ms"][1], "launches": prof["launches"][1]},
+                    "node_finalize": {"ms_total": prof["ms"][2], "launches": prof["launches"][2]},
+                }
+            else:
+                gate_bytes = 2.0 * E_local * H * 4              # read C e, write act (node tables are L2/MALL traffic)
+                out["kernels"] = {
+                    "edge_linear": {"ms_total": prof["ms"][0], "launches": prof["launches"][0]},
+                    "node_linear": {"ms_total": prof["ms"][1], "launches": prof["launches"][1]},
+                    "edge_gate_aggregate": {"ms_total": prof["ms"][2], "launches": prof["launches"][2],
+                                            "achieved_GBs": gate_bytes / g_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                                            "frac": gate_bytes / g_s / 1e9 / PEAK_HBM_GBS, "bound": "hbm",
+                                            "algorithmic_bytes_per_launch": gate_bytes},
+                }
+            out["kernels"].update({
                 "head": {"ms_total": prof["ms"][3], "launches": prof["launches"][3]},
                 "embed_misc": {"ms_total": prof["ms"][4], "launches": prof["launches"][4]},
                 "sum_ms_per_step": sum(prof["ms"]) / args.steps,
-            }
+            })
         if world == 1 and args.cpu_steps > 0:
             out["cpu_baseline"] = cpu_baseline(args.nodes, args.knn, args.cpu_steps, params)
         print(json.dumps(out), flush=True)

@@ -318,12 +318,16 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   {                                                                                   \
     _Pragma("unroll") for (int q2 = 0; q2 < 2; ++q2) {                                \
       const int fb_ = 32 * ((b) >> 1) + 8 * (2 * ((b) & 1) + q2) + 4 * hh;            \
-      if constexpr (!(ablate & 1)) {                                                  \
+      if constexpr (!(ablate & 1) && !(ablate & 256)) {                               \
         ga[buf][q2][0] = *reinterpret_cast<const v4f*>(nj + 2 * H + fb_);             \
-        ga[buf][q2][1] = *reinterpret_cast<const v4f*>(ni + 3 * H + fb_);             \
         ga[buf][q2][2] = *reinterpret_cast<const v4f*>(nj + H + fb_);                 \
       } else {                                                                        \
-        ga[buf][q2][0] = ga[buf][q2][1] = ga[buf][q2][2] = v4f{0.f, 0.f, 0.f, 0.f};   \
+        ga[buf][q2][0] = ga[buf][q2][2] = v4f{0.f, 0.f, 0.f, 0.f};                    \
+      }                                                                               \
+      if constexpr (!(ablate & 1) && !(ablate & 128)) {                               \
+        ga[buf][q2][1] = *reinterpret_cast<const v4f*>(ni + 3 * H + fb_);             \
+      } else {                                                                        \
+        ga[buf][q2][1] = v4f{0.f, 0.f, 0.f, 0.f};                                     \
       }                                                                               \
     }                                                                                 \
   }
@@ -628,6 +632,11 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     case 8: return launch_fused_t<FFp16, 8, FUSED_NW>(FUSED_ARGS);
     case 15: return launch_fused_t<FFp16, 15, FUSED_NW>(FUSED_ARGS);
     case 16: return launch_fused_t<FFp16, 16, FUSED_NW>(FUSED_ARGS);   // production code + phase timestamps
+    case 1: return launch_fused_t<FFp16, 1, FUSED_NW>(FUSED_ARGS);
+    case 2: return launch_fused_t<FFp16, 2, FUSED_NW>(FUSED_ARGS);
+    case 4: return launch_fused_t<FFp16, 4, FUSED_NW>(FUSED_ARGS);
+    case 128: return launch_fused_t<FFp16, 128, FUSED_NW>(FUSED_ARGS);
+    case 256: return launch_fused_t<FFp16, 256, FUSED_NW>(FUSED_ARGS);
     case 100: return launch_fused_t<FFp16, 0, 12 - FUSED_NW>(FUSED_ARGS);   // the other workgroup geometry (A/B)
     case 116: return launch_fused_t<FFp16, 16, 12 - FUSED_NW>(FUSED_ARGS);
     default: return hipErrorInvalidValue;

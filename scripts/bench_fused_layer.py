@@ -38,21 +38,28 @@ def run(e, h):
                                           P(scratch), st))
 
 
+# interleaved rounds (variants alternate inside one process; report median and min - cdna guide rule 24)
+ROUNDS, ITERS = 7, 5
+times = {m: [] for m in masks}
+e, h = e0.clone(), h0.clone()
+for r in range(ROUNDS + 1):
+    for mask in masks:
+        L.difusco_debug_set(0, mask)
+        run(e, h)
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(ITERS):
+            run(e, h)
+        t1.record()
+        torch.cuda.synchronize()
+        if r > 0:                       # round 0 = warm-up
+            times[mask].append(t0.elapsed_time(t1) / ITERS)
 for mask in masks:
-    L.difusco_debug_set(0, mask)
-    e, h = e0.clone(), h0.clone()
-    for _ in range(2):
-        run(e, h)
-    torch.cuda.synchronize()
-    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0.record()
-    for _ in range(10):
-        run(e, h)
-    t1.record()
-    torch.cuda.synchronize()
-    ms = t0.elapsed_time(t1) / 10
-    print(f"{prec} ablate={mask:2d}: {ms:.3f} ms per layer  (E={E}, {2*E*H*4/ms/1e6:.0f} GB/s algorithmic, "
-          f"{4*E*H*H*3/ms/1e9:.0f} TF issued)")
+    ts = sorted(times[mask])
+    ms = ts[len(ts) // 2]
+    print(f"{prec} ablate={mask:3d}: median {ms:.3f} ms  min {ts[0]:.3f}  max {ts[-1]:.3f} per layer  (E={E}, "
+          f"{2*E*H*4/ms/1e6:.0f} GB/s algorithmic, {4*E*H*H*3/ms/1e9:.0f} TF issued)")
 L.difusco_debug_set(0, 0)
 # the two workgroup geometries must give the same result (same arithmetic, same tile decomposition)
 outs = []
