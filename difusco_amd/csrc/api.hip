@@ -438,6 +438,7 @@ int difusco_debug_set_ptr(int key, void* p) {
 
 int difusco_debug_set(int key, int value) {
   if (key == 0) { difusco::g_fused_ablate = value; return DIFUSCO_OK; }
+  if (key == 2) { difusco::g_fused_variant = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }
 

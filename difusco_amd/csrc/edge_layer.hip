@@ -31,59 +31,9 @@
 // the first or last of its tile may continue in the neighbouring tile: it goes to part[tile][0|1];
 // segments strictly inside a tile are complete and go to direct[node].  node_finalize_kernel adds the
 // pieces of each node in tile order - deterministic, no atomics.
-#include "common.h"
-#include "kernels.h"
+#include "edge_layer_common.h"
 
 namespace difusco {
-
-typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
-typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef _Float16 v2h __attribute__((ext_vector_type(2)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-
-struct FBf16 {
-  typedef v8bf frag;
-  __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
-    v2f f = {a, b};
-    v2bf h = __builtin_convertvector(f, v2bf);
-    a -= (float)h[0];
-    b -= (float)h[1];
-    return __builtin_bit_cast(unsigned, h);
-  }
-  __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-struct FFp16 {
-  typedef v8h frag;
-  __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
-    v2f f = {a, b};
-    v2h h = __builtin_convertvector(f, v2h);
-    a -= (float)h[0];
-    b -= (float)h[1];
-    return __builtin_bit_cast(unsigned, h);
-  }
-  __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-
-// eight fp32 -> two planes of eight 16-bit values (hi, lo)
-template <typename T>
-__device__ __forceinline__ void split8(const float (&x)[8], typename T::frag& hi, typename T::frag& lo) {
-  float v[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) v[q] = x[q];
-  v4u h, l;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) h[q] = T::split_pair(v[2 * q], v[2 * q + 1]);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) l[q] = T::split_pair(v[2 * q], v[2 * q + 1]);
-  hi = __builtin_bit_cast(typename T::frag, h);
-  lo = __builtin_bit_cast(typename T::frag, l);
-}
 
 namespace fused {
 constexpr int H = 256;
@@ -113,14 +63,6 @@ struct Geo {
   static constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;  // 142336 (1 WG/CU) | 74752 (2 WG/CU)
 };
 }  // namespace fused
-
-// LDS element offset of (entry, half) inside a plane: 32-byte rows, halves swapped on odd 8-row groups
-__device__ __forceinline__ int wslot(int entry, int half) { return entry * 16 + ((half ^ ((entry >> 3) & 1)) << 3); }
-
-// sigmoid on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each)
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
 
 template <typename T, int ABL, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
@@ -158,8 +100,12 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
   // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
   unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define FUSED_STAMP(k) \
-  if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();
+#define FUSED_STAMP(k)                                                       \
+  if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();     \
+  if constexpr ((ABL & 512) != 0) {   /* experiment: matrix phases at raised issue priority */ \
+    if ((k) == 1 || (k) == 6) __builtin_amdgcn_s_setprio(1);                  \
+    if ((k) == 4 || (k) == 9) __builtin_amdgcn_s_setprio(0);                  \
+  }
   FUSED_STAMP(0)
 
   // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}] = two float4 of the tiled
@@ -625,6 +571,7 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
   if (n_edges <= 0) return hipSuccess;
 #define FUSED_ARGS e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, \
                    time_on_edge, part, direct, stream
+  if (g_fused_variant == 1) return launch_edge_layer_pipe(mode, FUSED_ARGS);
   if (mode == 1) return launch_fused_t<FBf16, 0, FUSED_NW>(FUSED_ARGS);
   if (mode != 3) return hipErrorInvalidValue;
   switch (g_fused_ablate) {   // profiling-only variants exist for the fp16 kernel
@@ -637,6 +584,7 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     case 4: return launch_fused_t<FFp16, 4, FUSED_NW>(FUSED_ARGS);
     case 128: return launch_fused_t<FFp16, 128, FUSED_NW>(FUSED_ARGS);
     case 256: return launch_fused_t<FFp16, 256, FUSED_NW>(FUSED_ARGS);
+    case 512: return launch_fused_t<FFp16, 512, FUSED_NW>(FUSED_ARGS);
     case 100: return launch_fused_t<FFp16, 0, 12 - FUSED_NW>(FUSED_ARGS);   // the other workgroup geometry (A/B)
     case 116: return launch_fused_t<FFp16, 16, 12 - FUSED_NW>(FUSED_ARGS);
     default: return hipErrorInvalidValue;

@@ -1,0 +1,66 @@
+// Shared pieces of the fused edge-layer kernels (edge_layer.hip, edge_layer_pipe.hip): 16-bit element traits,
+// fp32 -> two-plane split, LDS swizzle of the weight stages, fast sigmoid.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace difusco {
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+struct FBf16 {
+  typedef v8bf frag;
+  __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
+    v2f f = {a, b};
+    v2bf h = __builtin_convertvector(f, v2bf);
+    a -= (float)h[0];
+    b -= (float)h[1];
+    return __builtin_bit_cast(unsigned, h);
+  }
+  __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+struct FFp16 {
+  typedef v8h frag;
+  __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
+    v2f f = {a, b};
+    v2h h = __builtin_convertvector(f, v2h);
+    a -= (float)h[0];
+    b -= (float)h[1];
+    return __builtin_bit_cast(unsigned, h);
+  }
+  __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// eight fp32 -> two planes of eight 16-bit values (hi, lo)
+template <typename T>
+__device__ __forceinline__ void split8(const float (&x)[8], typename T::frag& hi, typename T::frag& lo) {
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = x[q];
+  v4u h, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) h[q] = T::split_pair(v[2 * q], v[2 * q + 1]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) l[q] = T::split_pair(v[2 * q], v[2 * q + 1]);
+  hi = __builtin_bit_cast(typename T::frag, h);
+  lo = __builtin_bit_cast(typename T::frag, l);
+}
+
+// LDS element offset of (entry, half) inside a plane: 32-byte rows, halves swapped on odd 8-row groups
+__device__ __forceinline__ int wslot(int entry, int half) { return entry * 16 + ((half ^ ((entry >> 3) & 1)) << 3); }
+
+// sigmoid on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+}  // namespace difusco
