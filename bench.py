@@ -52,27 +52,52 @@ def pmc_traffic_bytes(kernel_name):
     return None
 
 
-def cpu_baseline(n_nodes, k, steps, params):
+def cpu_baseline(wl, steps, params):
     """The CPU oracle (port of the reference op sequence, incl. V applied on E gathered rows) on a bounded
     sample: ONE graph of the same workload, 1 warm-up + `steps` timed denoise steps.  This leg is the only
     place where bench.py touches oracle/."""
     from oracle import difusco_oracle as O
-    from difusco_amd.synthetic import tsp_instance
-    pts, ei = tsp_instance(n_nodes, k, seed=1000)
-    pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
-    tab = O.CategoricalTables()
+    from difusco_amd.synthetic import er_mis_edge_index, tsp_instance
     g = torch.Generator().manual_seed(0)
-    xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
+    if wl["task"] == "mis":
+        n = 750
+        ei = torch.from_numpy(er_mis_edge_index(n, 0.15, seed=1000))
+        tab = O.CategoricalTables()
+        xt = (torch.randn(n, generator=g) > 0).float()
+        step = lambda xt, t1, t2: O.mis_categorical_denoise_step(params, tab, xt, t1, ei, t2, generator=g)
+        what = f"1 graph ER-{n} p=0.15 ({ei.shape[1]} directed edges incl. self loops)"
+    else:
+        pts, ei = tsp_instance(wl["nodes"], wl["knn"], seed=1000)
+        pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
+        what = f"1 graph TSP-{wl['nodes']} K={wl['knn']}"
+        if wl["diffusion"] == "gaussian":
+            tab = O.GaussianTables()
+            xt = torch.randn(ei.shape[1], generator=g)
+            step = lambda xt, t1, t2: O.tsp_gaussian_denoise_step(params, tab, pts, xt, t1, ei, t2)
+        else:
+            tab = O.CategoricalTables()
+            xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
+            step = lambda xt, t1, t2: O.tsp_categorical_denoise_step(params, tab, pts, xt, t1, ei, t2, generator=g)
     with torch.no_grad():
-        xt = O.tsp_categorical_denoise_step(params, tab, pts, xt, 1000, ei, 969, generator=g)
+        xt = step(xt, 1000, 969)
         t0 = time.perf_counter()
         for i in range(steps):
             t1, t2 = O.inference_schedule("cosine", 1000, 50, i + 1)
-            xt = O.tsp_categorical_denoise_step(params, tab, pts, xt, t1, ei, t2, generator=g)
+            xt = step(xt, t1, t2)
         dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "graph-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 graph TSP-{n_nodes} K={k} H={H} L={LAYERS} fp32, 1 warm-up + {steps} timed steps "
+            "sample": f"{what} H={H} L={LAYERS} fp32 {wl['diffusion']}, 1 warm-up + {steps} timed steps "
                       f"of the CPU oracle ({dt:.1f} s)"}
+
+
+# BASELINE.json configs[1..4].  tsp1000 is the configuration the metric is quoted on (the default; it fits one GPU
+# at 8 graphs per GPU); the others are the remaining single-GPU shards of the reference's configurations.
+WORKLOADS = {
+    "tsp1000": dict(task="tsp", diffusion="categorical", nodes=1000, knn=100, graphs_per_gpu=8),
+    "tsp500": dict(task="tsp", diffusion="categorical", nodes=500, knn=50, graphs_per_gpu=16),
+    "tsp10000": dict(task="tsp", diffusion="gaussian", nodes=10000, knn=100, graphs_per_gpu=1),
+    "mis": dict(task="mis", diffusion="categorical", nodes=None, knn=None, graphs_per_gpu=16),
+}
 
 
 def main():
@@ -80,9 +105,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nodes", type=int, default=1000)
-    ap.add_argument("--knn", type=int, default=100)
-    ap.add_argument("--graphs-per-gpu", type=int, default=8)
+    ap.add_argument("--workload", default="tsp1000", choices=sorted(WORKLOADS),
+                    help="tsp1000 = the configuration BASELINE.json's metric is quoted on (default); tsp500, "
+                         "tsp10000 (Gaussian diffusion, 1 graph per GPU) and mis (ER-[700,800], p=0.15) are the "
+                         "per-GPU shards of the other configurations")
+    ap.add_argument("--nodes", type=int, default=None, help="override the workload's node count (TSP)")
+    ap.add_argument("--knn", type=int, default=None, help="override the workload's neighbour count (TSP)")
+    ap.add_argument("--graphs-per-gpu", type=int, default=None, help="override the workload's graphs per GPU")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (0 = skip cpu_baseline)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-library HIP-event brackets")
     ap.add_argument("--no-fusion", action="store_true", help="unfused kernel sequence (A/B against the fused layer kernel)")
@@ -90,6 +119,12 @@ def main():
                     help="arithmetic of the E-row linears: exact fp32 MFMA, or fp32 split into 2/3 bf16 planes "
                          "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
     args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    for key in ("nodes", "knn", "graphs_per_gpu"):
+        if getattr(args, key) is not None:
+            wl[key] = getattr(args, key)
+    args.nodes, args.knn, args.graphs_per_gpu = wl["nodes"], wl["knn"], wl["graphs_per_gpu"]
+    gaussian, mis = wl["diffusion"] == "gaussian", wl["task"] == "mis"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,34 +151,52 @@ def main():
     from difusco_amd import _lib
     from difusco_amd.dist import GN_STATS_MODE, engine_from_broadcast, shard_range
     from difusco_amd.engine import DenoiseEngine
-    from difusco_amd.models import TSPModel
+    from difusco_amd.models import MISModel, TSPModel
     from difusco_amd.schedules import InferenceSchedule
-    from difusco_amd.synthetic import random_state_dict, tsp_batch
+    from difusco_amd.synthetic import er_mis_edge_index, random_state_dict, tsp_batch
 
     # frozen weights: rank 0 creates, RCCL broadcast of the packed blob over xGMI
-    params = random_state_dict(H, LAYERS, 2, seed=20240926) if rank == 0 or world == 1 else None
+    params = random_state_dict(H, LAYERS, 1 if gaussian else 2, seed=20240926) if rank == 0 or world == 1 else None
     if world > 1:
         engine = engine_from_broadcast(params, device, src=0, precision=args.precision, fused=not args.no_fusion)
     else:
         engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion)
-    margs = dict(diffusion_type="categorical", diffusion_schedule="linear", diffusion_steps=1000,
-                 inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn,
-                 n_layers=LAYERS, hidden_dim=H)
-    model = TSPModel(margs, engine=engine, seed=1234 + rank)
+    margs = dict(diffusion_type=wl["diffusion"], diffusion_schedule="linear", diffusion_steps=1000,
+                 inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn if not mis else -1,
+                 n_layers=LAYERS, hidden_dim=H, inference_trick="ddim")
+    model = (MISModel if mis else TSPModel)(margs, engine=engine, seed=1234 + rank)
 
     # this rank's shard of the global batch (weak scaling: graphs_per_gpu fixed)
     G_total = args.graphs_per_gpu * world
     lo, hi = shard_range(G_total, rank, world)
-    points, edge_index = tsp_batch(args.nodes, args.knn, range(lo, hi), device)
+    gen = torch.Generator().manual_seed(77 + rank)
+    if mis:
+        # Erdos-Renyi G(n, 0.15), n ~ U{700..800} per graph (data/README.md:60-68), + reversed copies + self loops
+        eis, n_off = [], 0
+        for gid in range(lo, hi):
+            n = int(np.random.default_rng(5000 + gid).integers(700, 801))
+            eis.append(er_mis_edge_index(n, 0.15, seed=1000 + gid) + n_off)
+            n_off += n
+        points, edge_index = None, torch.from_numpy(np.concatenate(eis, 1)).to(device)
+        N_local = n_off
+        xt = (torch.randn(N_local, generator=gen) > 0).float().to(device)
+    else:
+        points, edge_index = tsp_batch(args.nodes, args.knn, range(lo, hi), device)
+        N_local = points.shape[0]
+        xt = torch.randn(edge_index.shape[1], generator=gen)
+        xt = (xt if gaussian else (xt > 0).float()).to(device)
     G_local = hi - lo
     E_local = edge_index.shape[1]
-    gen = torch.Generator().manual_seed(77 + rank)
-    xt = (torch.randn(E_local, generator=gen) > 0).float().to(device)
     sched = InferenceSchedule("cosine", T=1000, inference_T=50)
 
     def one_step(i, xt):
         t1, t2 = sched(i % 49)                                  # never the final (t2 = 0) step: keeps xt binary
-        return model.categorical_denoise_step(points, xt, np.array([t1]), device, edge_index, target_t=np.array([t2]))
+        t1, t2 = np.array([t1]), np.array([t2])
+        if mis:
+            return model.categorical_denoise_step(xt, t1, device, edge_index, target_t=t2)
+        if gaussian:
+            return model.gaussian_denoise_step(points, xt, t1, device, edge_index, target_t=t2)
+        return model.categorical_denoise_step(points, xt, t1, device, edge_index, target_t=t2)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -178,14 +231,19 @@ def main():
     if rank == 0:
         value = G_total * args.steps / dt
         out = {
-            "metric": "denoising steps/sec (graphs x steps / s), TSP-1000 k-NN sparse categorical",
+            "metric": "denoising steps/sec (graphs x steps / s), " + (
+                "MIS ER-[700,800] sparse categorical" if mis else
+                f"TSP-{args.nodes} k-NN sparse {wl['diffusion']}"),
             "value": value, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"TSP-{args.nodes} k-NN K={args.knn} sparse categorical, cosine 50-step schedule, "
-                                   f"{args.graphs_per_gpu} graphs per GPU (global batch {G_total}), H={H}, {LAYERS} layers",
-                       "graphs_per_gpu": args.graphs_per_gpu, "global_batch": G_total, "nodes": args.nodes,
-                       "knn": args.knn, "edges_per_graph": args.nodes * args.knn, "gn_stats": GN_STATS_MODE,
+            "config": {"workload": (f"MIS Erdos-Renyi n~U[700,800] p=0.15 (+reverse edges, +self loops) sparse categorical"
+                                    if mis else f"TSP-{args.nodes} k-NN K={args.knn} sparse {wl['diffusion']}") +
+                                   f", cosine 50-step schedule, {args.graphs_per_gpu} graphs per GPU "
+                                   f"(global batch {G_total}), H={H}, {LAYERS} layers",
+                       "name": args.workload, "graphs_per_gpu": args.graphs_per_gpu, "global_batch": G_total,
+                       "nodes": args.nodes, "knn": args.knn, "nodes_rank0": N_local, "edges_rank0": E_local,
+                       "gn_stats": GN_STATS_MODE,
                        "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision,
                        "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3")},
         }
@@ -246,7 +304,7 @@ def main():
                 "sum_ms_per_step": sum(prof["ms"]) / args.steps,
             })
         if world == 1 and args.cpu_steps > 0:
-            out["cpu_baseline"] = cpu_baseline(args.nodes, args.knn, args.cpu_steps, params)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, params)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

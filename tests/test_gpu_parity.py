@@ -537,6 +537,84 @@ def test_full_size_properties_tsp500(dev, fused):
         assert torch.equal(one, o_seg[:E1])
 
 
+
+def test_full_size_properties_mis_er(dev):
+    """MIS shard at BASELINE size (4 Erdos-Renyi graphs n in [700,800], p=0.15, H=256, 12 layers; edges arrive
+    NOT row-sorted): (1) bitwise determinism, (2) the fused layer kernel and the unfused kernel sequence agree to
+    fp32 summation-order accuracy, (3) node outputs do not depend on the order of the edge list (the neighbour
+    sum is a set sum, gnn_encoder.py:177-191), (4) a graph run alone with per-graph statistics reproduces its rows
+    of the batch run with per-graph statistic segments, (5) outputs are {0,1} and finite."""
+    from difusco_amd import MISModel, _lib
+    from difusco_amd.graph import build_csr
+    from difusco_amd.synthetic import er_mis_edge_index
+    H, Lyr = 256, 12
+    p = O.init_params(H, Lyr, 2, seed=3)
+    sizes = [700, 741, 777, 800]
+    eis, off = [], 0
+    for k, n in enumerate(sizes):
+        eis.append(er_mis_edge_index(n, 0.15, seed=50 + k) + off)
+        off += n
+    N = off
+    ei = torch.from_numpy(np.concatenate(eis, 1)).to(dev)
+    g = torch.Generator().manual_seed(9)
+    xt = (torch.randn(N, generator=g) > 0).float().to(dev)
+    u = torch.rand(N, generator=g)
+    t, tt = np.array([400]), np.array([380])
+    mf = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev, fused=True)
+    mu = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev, fused=False)
+    a, la, pa = mf.categorical_denoise_step(xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    b, lb, pb = mf.categorical_denoise_step(xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    assert torch.equal(a, b) and torch.equal(la, lb)
+    assert torch.isfinite(la).all() and set(a.unique().tolist()) <= {0.0, 1.0}
+    c, lc, pc = mu.categorical_denoise_step(xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    print(f"MIS full size: fused vs unfused logits L_inf {(la - lc).abs().max().item():.3e}")
+    assert (la - lc).abs().max().item() < 5e-5 and (pa - pc).abs().max().item() < 5e-5
+    # edge-order invariance
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(1)).to(dev)
+    d, ld, pd = mf.categorical_denoise_step(xt, t, dev, ei[:, perm], target_t=tt, uniform=u, return_aux=True)
+    assert (la - ld).abs().max().item() < 5e-5
+    # per-graph statistic segments == the graph alone
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    gseg = build_csr(ei, N, dev, seg_rows=bounds)
+    post = np.zeros(8, dtype=np.float32)
+    post[:4] = mu.diffusion.posterior_constants(400, 380)
+    post[4] = 1.0
+    o_seg, l_seg, _ = mu.model.step(gseg, _lib.TASK_MIS, _lib.CATEGORICAL, xt, 400.0, post, xt_is_binary=True, rand=u,
+                                    want_pred=True, want_prob=True)
+    k = 2
+    lo, hi = int(bounds[k]), int(bounds[k + 1])
+    ei_k = torch.from_numpy(eis[k] - lo).to(dev)
+    one, l_one, _ = mu.categorical_denoise_step(xt[lo:hi], t, dev, ei_k, target_t=tt, uniform=u[lo:hi], return_aux=True)
+    assert torch.equal(l_one.reshape(-1, 2), l_seg.reshape(-1, 2)[lo:hi]) and torch.equal(one, o_seg[lo:hi])
+
+
+def test_full_size_properties_tsp10000_gaussian(dev):
+    """TSP-10000 / K=100 / Gaussian diffusion, one graph (E = 10^6, the 1 GB edge state of BASELINE configs[4]):
+    (1) bitwise determinism, (2) fused and unfused paths agree, (3) the DDIM update is the affine map
+    a (x_t - b eps) + c eps of the returned eps prediction (pl_meta_model.py:171-172), evaluated in fp32 with the
+    reference's operation order, (4) everything is finite."""
+    from difusco_amd import TSPModel
+    from difusco_amd.synthetic import tsp_instance
+    H, Lyr, N, K = 256, 12, 10000, 100
+    p = O.init_params(H, Lyr, 1, seed=5)
+    pts, ei = tsp_instance(N, K, seed=77)
+    pts, ei = torch.from_numpy(pts).to(dev), torch.from_numpy(ei).to(dev)
+    xt = torch.randn(ei.shape[1], generator=torch.Generator().manual_seed(6)).to(dev)
+    t, tt = np.array([600]), np.array([560])
+    mf = TSPModel(_args("gaussian", K, H=H, L=Lyr), p, device=dev, fused=True)
+    a, ea = mf.gaussian_denoise_step(pts, xt, t, dev, ei, target_t=tt, return_aux=True)
+    b, eb = mf.gaussian_denoise_step(pts, xt, t, dev, ei, target_t=tt, return_aux=True)
+    assert torch.equal(a, b) and torch.equal(ea, eb) and torch.isfinite(a).all() and torch.isfinite(ea).all()
+    ca, cb, cc = (float(v) for v in mf.diffusion.posterior_constants(600, 560, "ddim")[:3])
+    eps = ea.reshape(-1)
+    expect = torch.tensor(ca, device=dev) * (xt - torch.tensor(cb, device=dev) * eps) + torch.tensor(cc, device=dev) * eps
+    assert (a - expect).abs().max().item() <= 1e-6 * max(1.0, expect.abs().max().item())
+    mu = TSPModel(_args("gaussian", K, H=H, L=Lyr), p, device=dev, fused=False)
+    c, ec = mu.gaussian_denoise_step(pts, xt, t, dev, ei, target_t=tt, return_aux=True)
+    print(f"TSP-10000 gaussian: fused vs unfused eps L_inf {(ea - ec).abs().max().item():.3e}, |eps| max {ea.abs().max().item():.2f}")
+    assert (ea - ec).abs().max().item() < 5e-5 and (a - c).abs().max().item() < 5e-5
+
+
 def test_sampling_loop_runs(dev):
     """The 50-step loop end to end (pl_tsp_model.py:185-222) on a small graph with on-device Philox."""
     from difusco_amd import TSPModel
