@@ -87,7 +87,14 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x * WAVES + wave;
+  // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  (ABL & 1024):
+  // give every XCD one contiguous range of tiles, so the node-table rows its tiles gather stay in its L2.
+  int bid = blockIdx.x;
+  if constexpr ((ABL & 1024) != 0) {
+    const int nblk = gridDim.x, per = nblk >> 3, rem = nblk & 7, x = bid & 7;
+    bid = x * per + (x < rem ? x : rem) + (bid >> 3);
+  }
+  const int tile = bid * WAVES + wave;
   const int s_raw = tile * 32 + l31;
   const bool valid = s_raw < n_edges;
   const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}] = two float4 of the tiled
   // layout.  Cold HBM reads: they run
   // RING slabs ahead of the MFMAs in a register ring (plain loads stay in flight across barriers).
-  constexpr int RING = 4;
+  constexpr int RING = (ABL & 2048) != 0 ? 4 : 2;   // beside LDS-DMA staging every load is drained at the stage barrier: 2 is enough
   v4f er[RING][2];
 #pragma unroll
   for (int d = 0; d < RING; ++d) {
@@ -165,16 +172,52 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   // issue the loads of stage t+2 (pinned at the top by the sched_barrier: the register-pressure-driven scheduler
   // otherwise sinks them next to their use and exposes the L2 latency once per stage), multiply stage t, barrier.
   // The first GEMM 2 stage pair straddles the epilogue: stage NS1+1 is fetched after it, not held across it.
-#define FUSED_PIPE_BEGIN(t)                                         \
-  if ((t) + 1 < NSTAGE) FUSED_STORE_STAGE((t) + 1)                  \
-  if ((t) + 2 < NSTAGE && (t) + 2 != NS1 + 1) {                     \
-    FUSED_LOAD_STAGE((t) + 2)                                       \
-    __builtin_amdgcn_sched_barrier(0);                              \
+  // LDS-DMA staging (production; ABL & 2048 selects the older register-staged path for A/B): global_load_lds_dwordx4
+  // moves 1 KiB per wave instruction from global memory
+  // straight into the stage buffer - no staging registers, no ds_write.  The LDS image is the same swizzled image
+  // the register path builds: lane L of wave w, instruction i (0, 1) fills slot (2 w + i) * 64 + L of a plane, i.e.
+  // entry = (2 w + i) * 32 + (L >> 1), and fetches the half that belongs there (the XOR of wslot applied on the
+  // source side; both halves of an entry are adjacent in global memory, so coalescing is unchanged).
+  // Protocol: iteration t requests stage t+1 into the other buffer (everybody left it at the last barrier),
+  // multiplies stage t, then waits for its own requests (vmcnt(0)) before the barrier.
+  constexpr bool kDma = (ABL & 2048) == 0;   // (the e ring is declared above this point: see RING)
+  unsigned dvoff1 = 0, dvoff2 = 0;
+  if constexpr (kDma) {
+    const int entry0 = (2 * wave) * 32 + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
+    dvoff1 = (entry0 >> 8) * 4096 + (entry0 & 255) * 16 + half * 8;
+    dvoff2 = (entry0 >> 6) * 4096 + (entry0 & 63) * 16 + half * 8;
   }
-#define FUSED_PIPE_END(t) \
-  if ((t) + 1 < NSTAGE) __syncthreads();
+#define FUSED_DMA_STAGE(t)                                                                                   \
+  {                                                                                                          \
+    const unsigned short* sb = stage_base(t);                                                                \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                         \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+        const unsigned short* src = sb + pl * plane_stride + ((t) < NS1 ? dvoff1 : dvoff2) + i * 512;        \
+        unsigned short* dst = wbuf + ((t) & 1) * BUF + pl * PLANE + (2 * wave + i) * 512;                    \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,                 \
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);            \
+      }                                                                                                      \
+  }
+#define FUSED_PIPE_BEGIN(t)                                         \
+  if constexpr (kDma) {                                             \
+    if ((t) + 1 < NSTAGE) {                                         \
+      FUSED_DMA_STAGE((t) + 1)                                      \
+      __builtin_amdgcn_sched_barrier(0);                            \
+    }                                                               \
+  } else {                                                          \
+    if ((t) + 1 < NSTAGE) FUSED_STORE_STAGE((t) + 1)                \
+    if ((t) + 2 < NSTAGE && (t) + 2 != NS1 + 1) {                   \
+      FUSED_LOAD_STAGE((t) + 2)                                     \
+      __builtin_amdgcn_sched_barrier(0);                            \
+    }                                                               \
+  }
+#define FUSED_PIPE_END(t)                                                        \
+  if ((t) + 1 < NSTAGE) {                                                        \
+    if constexpr (kDma) __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */       \
+    __syncthreads();                                                             \
+  }
 
-  FUSED_LOAD_STAGE(0)
+  if constexpr (kDma) { FUSED_DMA_STAGE(0) } else { FUSED_LOAD_STAGE(0) }
 
   // layer parameters -> LDS (thread = feature)
   if (tid < H) {
@@ -191,8 +234,12 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   const float* nj = node4 + (long long)j * 4 * H;       // rows U | V | A | B
   const float* ni = node4 + (long long)i_node * 4 * H;
 
-  FUSED_STORE_STAGE(0)
-  FUSED_LOAD_STAGE(1)
+  if constexpr (kDma) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage 0 has landed
+  } else {
+    FUSED_STORE_STAGE(0)
+    FUSED_LOAD_STAGE(1)
+  }
   __syncthreads();
 
   FUSED_STAMP(1)
@@ -401,7 +448,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 
   FUSED_STAMP(6)
   // ================================ GEMM 2 (four output quarters of 64 features) ======================
-  FUSED_LOAD_STAGE(NS1 + 1)
+  if constexpr (!kDma) { FUSED_LOAD_STAGE(NS1 + 1) }
   constexpr bool skip_gemm2 = (ablate & 8) != 0;   // (barriers must still be executed by every wave)
   constexpr bool skip_out = (ablate & 32) != 0;    // GEMM 2 without residual read / e store
   constexpr bool skip_mm2 = (ablate & 64) != 0;    // GEMM 2 output path without its MFMAs
@@ -483,6 +530,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 #undef FUSED_STORE_STAGE
 #undef FUSED_PIPE_BEGIN
 #undef FUSED_PIPE_END
+#undef FUSED_DMA_STAGE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -585,6 +633,8 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     case 128: return launch_fused_t<FFp16, 128, FUSED_NW>(FUSED_ARGS);
     case 256: return launch_fused_t<FFp16, 256, FUSED_NW>(FUSED_ARGS);
     case 512: return launch_fused_t<FFp16, 512, FUSED_NW>(FUSED_ARGS);
+    case 1024: return launch_fused_t<FFp16, 1024, FUSED_NW>(FUSED_ARGS);
+    case 2048: return launch_fused_t<FFp16, 2048, FUSED_NW>(FUSED_ARGS);
     case 100: return launch_fused_t<FFp16, 0, 12 - FUSED_NW>(FUSED_ARGS);   // the other workgroup geometry (A/B)
     case 116: return launch_fused_t<FFp16, 16, 12 - FUSED_NW>(FUSED_ARGS);
     default: return hipErrorInvalidValue;

@@ -71,6 +71,13 @@ for mask in (0, 100):
     outs.append((e, h))
 L.difusco_debug_set(0, 0)
 print("geometry A/B max |diff| e, h:", (outs[0][0] - outs[1][0]).abs().max().item(), (outs[0][1] - outs[1][1]).abs().max().item())
+for mask in [int(m) for m in os.environ.get("CMP_MASKS", "").split(",") if m]:     # variants that must not change results
+    L.difusco_debug_set(0, mask)
+    e, h = e0.clone(), h0.clone()
+    run(e, h)
+    torch.cuda.synchronize()
+    L.difusco_debug_set(0, 0)
+    print(f"variant {mask} vs production max |diff| e, h:", (outs[0][0] - e).abs().max().item(), (outs[0][1] - h).abs().max().item())
 if len(sys.argv) > 3 and sys.argv[3] == 'nostamp':
     sys.exit(0)
 # phase timestamps (s_memtime, 100 MHz-class constant clock or shader clock - reported as raw ticks and as shares)
