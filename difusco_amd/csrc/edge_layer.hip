@@ -116,14 +116,36 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   FUSED_STAMP(0)
 
   // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}] = two float4 of the tiled
-  // layout.  Cold HBM reads: they run
-  // RING slabs ahead of the MFMAs in a register ring (plain loads stay in flight across barriers).
-  constexpr int RING = (ABL & 2048) != 0 ? 4 : 2;   // beside LDS-DMA staging every load is drained at the stage barrier: 2 is enough
+  // layout = 2 KiB per wave and slab, cold HBM reads.
+  //  * production: a register ring, RING slabs ahead of the MFMAs.
+  //  * (ABL & 4096, 4-wave geometry, experiment): LDS-DMA into the wave's own aggregation scratch, which is idle
+  //    during GEMM 1: slab ks+2 is requested in iteration ks and must have landed at the end of iteration ks+1 (see
+  //    FUSED_PIPE_END), each lane reads its own 16 bytes back.  Measured 2.5 % slower than the register ring
+  //    (0.942 vs 0.919 ms per layer): the extra LDS round trip costs more than the 16 registers it frees.
+  constexpr bool kDma = (ABL & 2048) == 0;                          // weight stages by LDS-DMA (else registers)
+  constexpr bool kDmaE = kDma && SPS == 1 && (ABL & 4096) != 0;     // e stream by LDS-DMA too (experiment)
+  constexpr int RING = kDma ? 2 : 4;   // beside LDS-DMA staging every load is drained at the stage barrier
   v4f er[RING][2];
+  // (buffer addressing: SGPR resource + 32-bit lane offset + SGPR/immediate offsets - no per-lane 64-bit pointers;
+  //  the instruction's immediate offset is added to the memory address AND to the LDS address)
+  const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(etile, 0, 32 * H * 4, 0x00020000);
+#define FUSED_DMA_E(ks)                                                                                      \
+  {                                                                                                          \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                \
+        rs_e, (__attribute__((address_space(3))) void*)(scr + ((ks) & 1) * 512), 16, loff * 4, (ks) * 2048, 0, 0);      \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                \
+        rs_e, (__attribute__((address_space(3))) void*)(scr + ((ks) & 1) * 512), 16, loff * 4, (ks) * 2048, 1024,       \
+        0);                                                                                                  \
+  }
+  if constexpr (kDmaE) {
+    FUSED_DMA_E(0)
+    FUSED_DMA_E(1)
+  } else {
 #pragma unroll
-  for (int d = 0; d < RING; ++d) {
-    er[d][0] = *reinterpret_cast<const v4f*>(etile + d * 512 + loff);
-    er[d][1] = *reinterpret_cast<const v4f*>(etile + (d * 512 + 256) + loff);
+    for (int d = 0; d < RING; ++d) {
+      er[d][0] = *reinterpret_cast<const v4f*>(etile + d * 512 + loff);
+      er[d][1] = *reinterpret_cast<const v4f*>(etile + (d * 512 + 256) + loff);
+    }
   }
 
   // ---- weight stage streaming ---------------------------------------------------------------------
@@ -180,23 +202,27 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   // source side; both halves of an entry are adjacent in global memory, so coalescing is unchanged).
   // Protocol: iteration t requests stage t+1 into the other buffer (everybody left it at the last barrier),
   // multiplies stage t, then waits for its own requests (vmcnt(0)) before the barrier.
-  constexpr bool kDma = (ABL & 2048) == 0;   // (the e ring is declared above this point: see RING)
   unsigned dvoff1 = 0, dvoff2 = 0;
   if constexpr (kDma) {
     const int entry0 = (2 * wave) * 32 + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
     dvoff1 = (entry0 >> 8) * 4096 + (entry0 & 255) * 16 + half * 8;
     dvoff2 = (entry0 >> 6) * 4096 + (entry0 & 63) * 16 + half * 8;
   }
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c_planes), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(o_planes), 0, 0x7fffffff, 0x00020000);
+  const int plane_bytes = (int)plane_stride * 2;
 #define FUSED_DMA_STAGE(t)                                                                                   \
   {                                                                                                          \
-    const unsigned short* sb = stage_base(t);                                                                \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                         \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
-        const unsigned short* src = sb + pl * plane_stride + ((t) < NS1 ? dvoff1 : dvoff2) + i * 512;        \
-        unsigned short* dst = wbuf + ((t) & 1) * BUF + pl * PLANE + (2 * wave + i) * 512;                    \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,                 \
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);            \
-      }                                                                                                      \
+    const int u_ = (t) - NS1;                                                                                \
+    const int sbase = (t) < NS1 ? SPS * (t) * 4096 * 2 : ((KPS * (u_ % SPQ)) * 4096 + 64 * (u_ / SPQ) * 16) * 2; \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                       \
+      unsigned short* d0 = wbuf + ((t) & 1) * BUF + pl * PLANE + (2 * wave) * 512;                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((t) < NS1 ? rs_c : rs_o, (__attribute__((address_space(3))) void*)d0, 16, \
+                                               ((t) < NS1 ? dvoff1 : dvoff2) * 2, sbase + pl * plane_bytes, 0, 0);      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((t) < NS1 ? rs_c : rs_o,                                      \
+                                               (__attribute__((address_space(3))) void*)d0, 16,              \
+                                               ((t) < NS1 ? dvoff1 : dvoff2) * 2, sbase + pl * plane_bytes, 1024, 0);   \
+    }                                                                                                        \
   }
 #define FUSED_PIPE_BEGIN(t)                                         \
   if constexpr (kDma) {                                             \
@@ -211,9 +237,14 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
       __builtin_amdgcn_sched_barrier(0);                            \
     }                                                               \
   }
+  // end of iteration t: the requests of stage t+1 must have landed before the barrier.  In GEMM 1 with the e
+  // stream on the DMA queue as well, the two youngest requests are slab t+2 of e, which may stay in flight.
 #define FUSED_PIPE_END(t)                                                        \
   if ((t) + 1 < NSTAGE) {                                                        \
-    if constexpr (kDma) __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */       \
+    if constexpr (kDma) {                                                        \
+      if (kDmaE && (t) + 2 < 16) __builtin_amdgcn_s_waitcnt(0x0F72); /* vmcnt(2) */ \
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                       /* vmcnt(0) */ \
+    }                                                                            \
     __syncthreads();                                                             \
   }
 
@@ -260,13 +291,27 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 #pragma unroll
     for (int sub = 0; sub < SPS; ++sub) {
       const int ks = SPS * t + sub;
-      const v4f c0 = er[ks % RING][0], c1 = er[ks % RING][1];
-      if (ks + RING < 16) {
-        er[ks % RING][0] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512 + loff);
-        er[ks % RING][1] = *reinterpret_cast<const v4f*>(etile + ((ks + RING) * 512 + 256) + loff);
+      v4f c0, c1;
+      if constexpr (kDmaE) {
+        c0 = *reinterpret_cast<const v4f*>(scr + (ks & 1) * 512 + loff);
+        c1 = *reinterpret_cast<const v4f*>(scr + ((ks & 1) * 512 + 256) + loff);
+      } else {
+        c0 = er[ks % RING][0];
+        c1 = er[ks % RING][1];
+        if (ks + RING < 16) {
+          er[ks % RING][0] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512 + loff);
+          er[ks % RING][1] = *reinterpret_cast<const v4f*>(etile + ((ks + RING) * 512 + 256) + loff);
+        }
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       split8<T>(xs, xh[sub], xl[sub]);
+      if constexpr (kDmaE) {   // the slot is free once its values sit in registers: request slab ks + 2 into it
+        if (ks + 2 < 16) {
+          __builtin_amdgcn_sched_barrier(0);
+          FUSED_DMA_E(ks + 2)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     // 8 SPS weight blocks (bi = sub * 8 + nb), A fragments read from LDS two blocks ahead of their MFMAs
     const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
@@ -531,6 +576,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 #undef FUSED_PIPE_BEGIN
 #undef FUSED_PIPE_END
 #undef FUSED_DMA_STAGE
+#undef FUSED_DMA_E
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -635,6 +681,7 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     case 512: return launch_fused_t<FFp16, 512, FUSED_NW>(FUSED_ARGS);
     case 1024: return launch_fused_t<FFp16, 1024, FUSED_NW>(FUSED_ARGS);
     case 2048: return launch_fused_t<FFp16, 2048, FUSED_NW>(FUSED_ARGS);
+    case 4096: return launch_fused_t<FFp16, 4096, FUSED_NW>(FUSED_ARGS);
     case 100: return launch_fused_t<FFp16, 0, 12 - FUSED_NW>(FUSED_ARGS);   // the other workgroup geometry (A/B)
     case 116: return launch_fused_t<FFp16, 16, 12 - FUSED_NW>(FUSED_ARGS);
     default: return hipErrorInvalidValue;
