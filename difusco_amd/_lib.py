@@ -82,6 +82,9 @@ def lib():
                                                 ctypes.c_uint64, ctypes.c_uint64, f32p, f32p, i64, vp]
     L.difusco_gaussian_posterior.argtypes = [f32p, f32p, ctypes.POINTER(ctypes.c_float), i32, f32p,
                                              ctypes.c_uint64, ctypes.c_uint64, f32p, i64, vp]
+    L.difusco_tsp_merge_workspace_bytes.argtypes = [i64, ctypes.POINTER(ctypes.c_size_t)]
+    L.difusco_tsp_merge_tour.argtypes = [i32, i64, vp, vp, f32p, f32p, vp, ctypes.c_size_t, vp,
+                                         ctypes.POINTER(i64), ctypes.POINTER(i32), vp]
     if L.difusco_abi_version() != ABI_VERSION:
         raise DifuscoHipError(f"ABI version mismatch: library {L.difusco_abi_version()} != binding {ABI_VERSION}")
     _lib = L

@@ -28,6 +28,21 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(DIFUSCO_EHIP, "%s: %s", #expr, hipGetErrorString(e_));  \
   } while (0)
 
+}  // namespace
+
+namespace difusco {
+// error reporting for the other translation units of the library (same thread-local message buffer)
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace difusco
+
+namespace {
+
 constexpr int64_t kAlignFloats = 64;  // every packed tensor starts on a 256-byte boundary
 
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

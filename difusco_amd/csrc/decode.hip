@@ -1,0 +1,290 @@
+// Heatmap -> tour: the greedy edge insertion that runs right after the sampling loop on every TSP sample
+// (difusco/utils/tsp_utils.py:89-145 `merge_tours`, difusco/utils/cython_merge/cython_merge.pyx:19-104 `merge_cython`).
+//
+// The reference densifies the E-entry heatmap to N x N (A + A^T), divides by the N x N distance matrix and
+// argsorts all N^2 entries on the host: 10^8 elements per TSP-10000 sample.  Only entries that are edges of the
+// sparse graph (in either direction) are non-zero, and the walk over the sorted list ends after N-1 successful
+// insertions, long before the zero entries - so the same tour comes out of the E candidate pairs alone:
+//
+//   device  1. key = min(i,j) * N + max(i,j) per directed edge; radix sort (rocPRIM) brings the two directions
+//              of a pair together, pairs in flat-index order;
+//           2. per pair: S = fl32(A_ij + A_ji) (the reference adds the two float32 matrices, tsp_utils.py:108-114),
+//              score = double(S) / ||p_i - p_j||_2 in float64 (cython_merge.pyx:21,37), self loops set aside;
+//           3. stable radix sort by score, descending (ties keep flat-index order);
+//   host    4. the reference's route_begin / route_end bookkeeping over the sorted pairs (cython_merge.pyx:46-96),
+//              closing edge, and the walk from node 0 that always takes the larger unvisited neighbour
+//              (tsp_utils.py:134-141).
+//
+// `merge_iterations` reproduces the reference's count over its dense list: the self entries (score -inf, sorted
+// first) + two entries per pair before the terminating one + 1.  If the candidate pairs with a positive score do
+// not suffice for N-1 insertions the reference continues into its zero-valued entries, whose order is whatever
+// numpy's unstable argsort leaves - not reproducible; this implementation then walks the zero block in flat-index
+// order (a stable sort's order, as the CPU oracle does) and then the negative-score candidates, and reports
+// completed = 0 so that callers (and tests) know the tour is outside the regime pinned to the reference.  In that
+// regime merge_iterations counts the entries this implementation looked at, not the reference's.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <unordered_set>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/difusco_hip.h"
+#include "kernels.h"
+
+namespace difusco {
+namespace {
+
+__global__ void pair_key_kernel(const int* __restrict__ row, const int* __restrict__ col, long long n_edges, long long n,
+                                unsigned long long* __restrict__ key, unsigned* __restrict__ val) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const long long i = row[e], j = col[e];
+  const long long lo = i < j ? i : j, hi = i < j ? j : i;
+  key[e] = (unsigned long long)(lo * n + hi);
+  val[e] = (unsigned)e;
+}
+
+// One thread per position of the pair-sorted edge list.  The first position of a run of equal keys owns the
+// pair: it sums the run's heat in float32 (a_ij first when both directions exist, like A + A^T evaluated at
+// (i,j), i < j; float addition commutes, so (j,i) gets the same value) and emits score + packed (i,j).
+// Everything else (non-heads, self loops) gets score = -inf and sorts to the end.
+__global__ void pair_score_kernel(const unsigned long long* __restrict__ key, const unsigned* __restrict__ val,
+                                  const float* __restrict__ heat, const float* __restrict__ points, long long n_edges,
+                                  long long n, double* __restrict__ score, unsigned long long* __restrict__ pair,
+                                  unsigned* __restrict__ counters) {   // [0] pairs, [1] self loops with S > 0
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_edges) return;
+  const unsigned long long k = key[p];
+  const double ninf = -std::numeric_limits<double>::infinity();
+  score[p] = ninf;
+  pair[p] = k;
+  if (p > 0 && key[p - 1] == k) return;
+  float s = heat[val[p]];
+  long long q = p + 1;
+  while (q < n_edges && key[q] == k) {
+    s += heat[val[q]];
+    ++q;
+  }
+  const long long lo = (long long)(k / (unsigned long long)n), hi = (long long)(k % (unsigned long long)n);
+  if (lo == hi) {
+    // diagonal of A + A^T: A_ii + A_ii (tsp_utils.py:108-114); score -S/0 = -inf for S > 0 -> sorted first, skipped
+    const float d = s + s;
+    if (d > 0.0f) atomicAdd(&counters[1], 1u);
+    return;
+  }
+  const double dx = (double)points[2 * lo] - (double)points[2 * hi];
+  const double dy = (double)points[2 * lo + 1] - (double)points[2 * hi + 1];
+  const double dist = sqrt(dx * dx + dy * dy);
+  score[p] = (double)s / dist;
+  pair[p] = ((unsigned long long)lo << 32) | (unsigned long long)hi;
+  atomicAdd(&counters[0], 1u);
+}
+
+struct Carve {
+  unsigned long long *key_a, *key_b, *pair_a, *pair_b;
+  unsigned *val_a, *val_b, *counters;
+  double *score_a, *score_b;
+  void* temp;
+  size_t temp_bytes, total;
+};
+
+size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+hipError_t carve(void* base, long long E, Carve* c) {
+  size_t t1 = 0, t2 = 0;
+  hipError_t er = rocprim::radix_sort_pairs(nullptr, t1, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                            (unsigned*)nullptr, (unsigned*)nullptr, (size_t)E, 0, 64, 0, false);
+  if (er != hipSuccess) return er;
+  er = rocprim::radix_sort_pairs_desc(nullptr, t2, (double*)nullptr, (double*)nullptr, (unsigned long long*)nullptr,
+                                      (unsigned long long*)nullptr, (size_t)E, 0, 64, 0, false);
+  if (er != hipSuccess) return er;
+  c->temp_bytes = t1 > t2 ? t1 : t2;
+  size_t cur = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = cur;
+    cur += up256(bytes);
+    return base ? (void*)((char*)base + at) : (void*)nullptr;
+  };
+  c->key_a = (unsigned long long*)take(8 * E);
+  c->key_b = (unsigned long long*)take(8 * E);
+  c->pair_a = (unsigned long long*)take(8 * E);
+  c->pair_b = (unsigned long long*)take(8 * E);
+  c->score_a = (double*)take(8 * E);
+  c->score_b = (double*)take(8 * E);
+  c->val_a = (unsigned*)take(4 * E);
+  c->val_b = (unsigned*)take(4 * E);
+  c->counters = (unsigned*)take(256);
+  c->temp = take(c->temp_bytes);
+  c->total = cur;
+  return hipSuccess;
+}
+
+// cython_merge.pyx:107-120 (path compression included)
+int find_root(std::vector<int>& link, int i) {
+  int r = i;
+  while (link[r] != r) r = link[r];
+  while (link[i] != r) {
+    const int nx = link[i];
+    link[i] = r;
+    i = nx;
+  }
+  return r;
+}
+
+}  // namespace
+}  // namespace difusco
+
+extern "C" {
+
+int difusco_tsp_merge_workspace_bytes(int64_t n_edges, size_t* bytes) {
+  if (!bytes || n_edges < 0) return difusco::set_error(DIFUSCO_EINVAL, "tsp_merge_workspace_bytes: bad arguments");
+  difusco::Carve c;
+  hipError_t er = difusco::carve(nullptr, n_edges > 0 ? n_edges : 1, &c);
+  if (er != hipSuccess) return difusco::set_error(DIFUSCO_EHIP, "rocprim temp size: %s", hipGetErrorString(er));
+  *bytes = c.total;
+  return DIFUSCO_OK;
+}
+
+int difusco_tsp_merge_tour(int n_nodes, int64_t n_edges, const int32_t* row, const int32_t* col, const float* heat,
+                           const float* points, void* workspace, size_t workspace_bytes, int32_t* tour_out,
+                           int64_t* merge_iterations, int32_t* completed, void* stream) {
+  using namespace difusco;
+  if (n_nodes < 3 || n_edges <= 0 || !row || !col || !heat || !points || !workspace || !tour_out)
+    return set_error(DIFUSCO_EINVAL, "tsp_merge_tour: needs n_nodes >= 3, n_edges > 0 and non-null arrays");
+  if (n_edges > 0xffffffffLL) return set_error(DIFUSCO_EINVAL, "tsp_merge_tour: more than 2^32 edges in one graph");
+  const long long E = n_edges, N = n_nodes;
+  Carve c;
+  hipError_t er = carve(workspace, E, &c);
+  if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "rocprim temp size: %s", hipGetErrorString(er));
+  if (workspace_bytes < c.total)
+    return set_error(DIFUSCO_EINVAL, "tsp_merge_tour: workspace %zu < %zu bytes", workspace_bytes, c.total);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((E + 255) / 256);
+  int key_bits = 1;
+  while (key_bits < 64 && (1ULL << key_bits) < (unsigned long long)(N * N)) ++key_bits;
+
+  hipLaunchKernelGGL(pair_key_kernel, dim3(grid), dim3(256), 0, st, row, col, E, N, c.key_a, c.val_a);
+  size_t tb = c.temp_bytes;
+  er = rocprim::radix_sort_pairs(c.temp, tb, c.key_a, c.key_b, c.val_a, c.val_b, (size_t)E, 0, key_bits, st, false);
+  if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "radix_sort_pairs: %s", hipGetErrorString(er));
+  er = hipMemsetAsync(c.counters, 0, 256, st);
+  if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "memset: %s", hipGetErrorString(er));
+  hipLaunchKernelGGL(pair_score_kernel, dim3(grid), dim3(256), 0, st, c.key_b, c.val_b, heat, points, E, N, c.score_a,
+                     c.pair_a, c.counters);
+  tb = c.temp_bytes;
+  er = rocprim::radix_sort_pairs_desc(c.temp, tb, c.score_a, c.score_b, c.pair_a, c.pair_b, (size_t)E, 0, 64, st, false);
+  if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "radix_sort_pairs_desc: %s", hipGetErrorString(er));
+  unsigned counters[2] = {0, 0};
+  er = hipMemcpyAsync(counters, c.counters, sizeof(counters), hipMemcpyDeviceToHost, st);
+  if (er == hipSuccess) er = hipStreamSynchronize(st);
+  if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "counters: %s", hipGetErrorString(er));
+  const size_t n_pairs = counters[0];
+  std::vector<unsigned long long> pairs(n_pairs);
+  std::vector<double> scores(n_pairs);
+  if (n_pairs) {
+    er = hipMemcpyAsync(pairs.data(), c.pair_b, 8 * n_pairs, hipMemcpyDeviceToHost, st);
+    if (er == hipSuccess) er = hipMemcpyAsync(scores.data(), c.score_b, 8 * n_pairs, hipMemcpyDeviceToHost, st);
+    if (er == hipSuccess) er = hipStreamSynchronize(st);
+    if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "sorted pairs: %s", hipGetErrorString(er));
+  }
+
+  // ---- host: greedy insertion (cython_merge.pyx:26-104) -------------------------------------------------
+  std::vector<int> route_begin(N), route_end(N), nb0(N, -1), nb1(N, -1);
+  for (int v = 0; v < n_nodes; ++v) route_begin[v] = route_end[v] = v;
+  auto link_nodes = [&](int a, int b) {
+    (nb0[a] < 0 ? nb0[a] : nb1[a]) = b;
+    (nb0[b] < 0 ? nb0[b] : nb1[b]) = a;
+  };
+  long long merge_count = 0, iterations = counters[1];   // the -inf self entries come first in the dense order
+  int within = 0;
+  auto try_insert = [&](int i, int j) -> bool {
+    const int begin_i = find_root(route_begin, i), end_i = find_root(route_end, i);
+    const int begin_j = find_root(route_begin, j), end_j = find_root(route_end, j);
+    if (begin_i == begin_j) return false;
+    if (i != begin_i && i != end_i) return false;
+    if (j != begin_j && j != end_j) return false;
+    link_nodes(i, j);
+    ++merge_count;
+    if (i == begin_i && j == end_j) {
+      route_begin[begin_i] = begin_j;
+      route_end[end_j] = end_i;
+    } else if (i == end_i && j == begin_j) {
+      route_begin[begin_j] = begin_i;
+      route_end[end_i] = end_j;
+    } else if (i == begin_i && j == begin_j) {
+      route_begin[begin_i] = end_j;
+      route_begin[begin_j] = end_j;
+      route_begin[end_j] = end_j;
+      route_end[end_j] = end_i;
+      route_end[begin_j] = end_i;
+    } else {   // i == end_i && j == end_j
+      route_end[end_i] = begin_j;
+      route_begin[begin_j] = begin_i;
+      route_begin[end_j] = begin_i;
+      route_end[end_j] = begin_j;
+      route_end[begin_j] = begin_j;
+    }
+    return true;
+  };
+  size_t k = 0;
+  for (; k < n_pairs && merge_count < N - 1; ++k) {
+    if (!(scores[k] > 0.0)) break;                       // the pinned regime ends with the positive scores
+    const int i = (int)(pairs[k] >> 32), j = (int)(pairs[k] & 0xffffffffULL);
+    // dense order: (i,j) and (j,i) are adjacent with equal scores; the first one met does the insertion
+    iterations += 1;
+    try_insert(i, j);
+    if (merge_count == N - 1) break;
+    iterations += 1;
+  }
+  if (merge_count == N - 1) within = 1;
+  // Outside the pinned regime.  The dense list continues with its zero block (all entries with S == 0: the pairs
+  // that are not edges of the sparse graph, and candidates whose heat sums to exactly 0), then the entries with
+  // S < 0 (Gaussian heat can be negative) by decreasing score.  The reference's order INSIDE the zero block is an
+  // accident of numpy's unstable argsort; here it is flat-index order (what a stable sort gives, and what
+  // oracle/tsp_decode_oracle.py does): pairs (a, b), a < b, lexicographic.  Only path end points can be joined, so
+  // the scan walks end points instead of all N^2 / 2 pairs.
+  if (merge_count < N - 1) {
+    std::unordered_set<unsigned long long> negative;
+    for (size_t q = k; q < n_pairs; ++q)
+      if (scores[q] < 0.0) negative.insert(pairs[q]);
+    for (int a = 0; a < n_nodes && merge_count < N - 1; ++a) {
+      if (nb1[a] >= 0) continue;
+      for (int b = a + 1; b < n_nodes && merge_count < N - 1; ++b) {
+        if (nb1[b] >= 0) continue;
+        if (!negative.empty() && negative.count(((unsigned long long)a << 32) | (unsigned long long)b)) continue;
+        if (try_insert(a, b) && nb1[a] >= 0) break;
+      }
+    }
+    for (; k < n_pairs && merge_count < N - 1; ++k) {
+      if (!(scores[k] < 0.0)) continue;
+      try_insert((int)(pairs[k] >> 32), (int)(pairs[k] & 0xffffffffULL));
+    }
+  }
+  if (merge_count != N - 1) return set_error(DIFUSCO_EINVAL, "tsp_merge_tour: could not assemble a Hamiltonian path");
+  const int final_begin = find_root(route_begin, 0), final_end = find_root(route_end, 0);
+  link_nodes(final_end, final_begin);
+  // tsp_utils.py:134-141: walk from node 0, always to the larger-numbered neighbour that is not the previous node
+  tour_out[0] = 0;
+  int prev = -1, cur = 0;
+  for (int step = 1; step <= n_nodes; ++step) {
+    int a = nb0[cur], b = nb1[cur], nxt;
+    if (prev < 0) nxt = a > b ? a : b;
+    else if (a == prev && b == prev) nxt = a;            // (2-cycles cannot occur for N >= 3)
+    else if (a == prev) nxt = b;
+    else if (b == prev) nxt = a;
+    else nxt = a > b ? a : b;
+    tour_out[step] = nxt;
+    prev = cur;
+    cur = nxt;
+  }
+  if (merge_iterations) *merge_iterations = iterations;
+  if (completed) *completed = within;
+  return DIFUSCO_OK;
+}
+
+}  // extern "C"

@@ -4,6 +4,9 @@
 
 namespace difusco {
 
+// sets the message returned by difusco_last_error() and returns `code` (api.hip)
+int set_error(int code, const char* fmt, ...);
+
 // Tiled ("MFMA native") layout of an [E, 256] fp32 edge-feature matrix, used by the fused path.
 // Tile = 32 consecutive edges = 8192 floats laid out [slab ks = f/16 (16)][i = (f/8)%2][lane = ((f/4)%2)*32 + s%32 (64)][q = f%4]:
 // the float4 that lane (s%32, hh) of a wavefront feeds to / receives from a 32x32x16 MFMA for slab ks is at

@@ -1,0 +1,57 @@
+"""Heatmap -> tour on the GPU box: drop-in for ``merge_tours`` of the reference
+(``difusco/utils/tsp_utils.py:89-145``), sparse graphs only.
+
+Same signature and return value as the reference function: ``(tours, merge_iterations)`` with one closed tour
+(list starting and ending at node 0) per parallel sample and the mean of the per-sample iteration counters.  The
+work goes through ``difusco_tsp_merge_tour`` of libdifusco_hip.so (pair keys, scores and the two sorts on the GPU,
+the reference's route bookkeeping on the host); there is no CPU fallback.  Keyword-only extensions: ``device``,
+``return_completed`` (adds the per-sample flag that says whether the tour was assembled from positive-score
+candidate pairs, the regime pinned against the reference)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _dev(x, dtype, device):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    return x.to(device=device, dtype=dtype).contiguous()
+
+
+def merge_tours(adj_mat, np_points, edge_index_np, sparse_graph=False, parallel_sampling=1, *, device="cuda:0",
+                return_completed=False):
+    """``adj_mat``: [parallel_sampling * E] (or [parallel_sampling, E]) heat values in the edge order of
+    ``edge_index_np`` ([2, E], the ONE graph's edges); ``np_points`` [N, 2].  numpy arrays or torch tensors."""
+    if not sparse_graph:
+        raise NotImplementedError("the MI355X decode path covers the sparse (k-NN) heatmap; dense TSP-50/100 heatmaps "
+                                  "are the reference's CPU plumbing case")
+    device = torch.device(device)
+    L = _lib.lib()
+    ei = _dev(edge_index_np, torch.int32, device)
+    pts = _dev(np_points, torch.float32, device)
+    heat = _dev(adj_mat, torch.float32, device).reshape(parallel_sampling, -1)
+    n, E = pts.shape[0], ei.shape[1]
+    if heat.shape[1] != E:
+        raise ValueError(f"adj_mat holds {heat.shape[1]} values per sample for {E} edges")
+    nbytes = ctypes.c_size_t()
+    _lib.check(L.difusco_tsp_merge_workspace_bytes(E, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    tours, iters, done = [], [], []
+    row, col = ei[0].contiguous(), ei[1].contiguous()
+    for s in range(parallel_sampling):
+        tour = np.empty(n + 1, dtype=np.int32)
+        it, ok = ctypes.c_int64(), ctypes.c_int32()
+        _lib.check(L.difusco_tsp_merge_tour(n, E, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()),
+                                            ctypes.c_void_p(heat[s].data_ptr()), ctypes.c_void_p(pts.data_ptr()),
+                                            ctypes.c_void_p(ws.data_ptr()), nbytes.value,
+                                            tour.ctypes.data_as(ctypes.c_void_p), ctypes.byref(it), ctypes.byref(ok),
+                                            stream))
+        tours.append(tour.tolist())
+        iters.append(it.value)
+        done.append(bool(ok.value))
+    merge_iterations = float(np.mean(iters))
+    return (tours, merge_iterations, done) if return_completed else (tours, merge_iterations)

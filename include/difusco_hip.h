@@ -210,6 +210,21 @@ int difusco_gaussian_posterior(const float* pred, const float* xt, const float* 
                                int rand_mode, const float* rand, uint64_t seed, uint64_t offset,
                                float* xt_out, int64_t n, void* stream);
 
+/* ---- heatmap -> tour: the greedy edge insertion the reference runs on the host right after the
+ * sampling loop, difusco/utils/tsp_utils.py:89-145 (merge_tours) + utils/cython_merge/cython_merge.pyx:19-104
+ * (merge_cython), restricted to the E entries of the sparse heatmap instead of the N x N densification.
+ * ONE graph per call, node ids 0..n_nodes-1 (the caller slices a batch).  row/col/heat/points/workspace are DEVICE
+ * pointers: row[e] -> col[e] are the directed edges of the sparse graph in any order, heat[e] the final x_t
+ * (+1e-6 / *0.5+0.5 already applied, pl_tsp_model.py:219-222), points [n_nodes,2] float32.  tour_out (HOST,
+ * n_nodes + 1 ints) receives the closed tour starting and ending at node 0 (tsp_utils.py:134-141);
+ * *merge_iterations the reference's counter over its dense sorted list; *completed = 1 when the N-1 insertions
+ * were found among candidate pairs with a positive score (the regime in which the result is pinned to the
+ * reference), 0 when the fallback had to finish the tour.  Blocks until done (synchronises `stream`). */
+int difusco_tsp_merge_workspace_bytes(int64_t n_edges, size_t* bytes);
+int difusco_tsp_merge_tour(int n_nodes, int64_t n_edges, const int32_t* row, const int32_t* col, const float* heat,
+                           const float* points, void* workspace, size_t workspace_bytes, int32_t* tour_out,
+                           int64_t* merge_iterations, int32_t* completed, void* stream);
+
 /* ---- in-library profiler (bench.py): HIP events on the launch stream around every kernel launch of
  * difusco_denoise_step, summed per category.  Categories: 0 edge-row linear (rows = n_edges),
  * 1 node-row linear, 2 edge gate/aggregate, 3 head (GroupNorm+conv+posterior, 3 launches),

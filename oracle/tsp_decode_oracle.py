@@ -1,0 +1,97 @@
+"""CPU restatement of the reference's heatmap -> tour decode.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py):
+imported by tests/ and by the cpu_baseline leg of scripts/bench_decode.py, never by the product path.
+
+Follows ``difusco/utils/tsp_utils.py:89-145`` (``merge_tours``: A + A^T densification in float32, walk from node 0)
+and ``difusco/utils/cython_merge/cython_merge.pyx:19-120`` (``merge_cython``: float64 distance matrix, argsort of
+-A/d over all N^2 entries, route_begin/route_end bookkeeping with path compression).  Parity pin: the fixtures
+``tests/golden/tsp_decode_*.npz`` were produced by the reference's own functions (the .pyx compiled with the
+Cython of this image), see tests/golden/make_golden_decode.py and PROVENANCE.md.
+
+One deliberate difference: numpy's default argsort is unstable, so the reference's order among EXACTLY equal
+scores (the zero entries of non-edges, the two orientations of a pair) is an implementation accident.  This
+restatement sorts stably (ties in flat-index order); the tour is invariant under the orientation order, and the
+fixtures only pin cases that finish before the zero entries (``completed``)."""
+import numpy as np
+
+
+def _find(link, i):
+    r = i
+    while link[r] != r:
+        r = link[r]
+    while link[i] != r:
+        link[i], i = r, link[i]
+    return r
+
+
+def merge_dense(points, adj_mat):
+    """cython_merge.pyx:19-104 on a dense symmetric matrix.  Returns (A_tour [N,N] 0/1, merge_iterations,
+    completed) where completed says that the N-1 insertions happened on entries with a negative sort key
+    (positive heat / distance), i.e. before the zero block."""
+    pts = np.asarray(points, dtype=np.float64)
+    adj = np.asarray(adj_mat, dtype=np.float64)
+    n = pts.shape[0]
+    dist = np.linalg.norm(pts[:, None] - pts, axis=-1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        key = (-adj / dist).flatten()
+    order = np.argsort(key, kind="stable")
+    begin, end = np.arange(n), np.arange(n)
+    A = np.zeros((n, n))
+    it = cnt = 0
+    completed = True
+    for edge in order:
+        it += 1
+        i, j = int(edge // n), int(edge % n)
+        bi, ei_, bj, ej = _find(begin, i), _find(end, i), _find(begin, j), _find(end, j)
+        if bi == bj or (i != bi and i != ei_) or (j != bj and j != ej):
+            continue
+        if not key[edge] < 0:
+            completed = False
+        A[i, j] = A[j, i] = 1
+        cnt += 1
+        if i == bi and j == ej:
+            begin[bi] = bj
+            end[ej] = ei_
+        elif i == ei_ and j == bj:
+            begin[bj] = bi
+            end[ei_] = ej
+        elif i == bi and j == bj:
+            begin[bi] = ej
+            begin[bj] = ej
+            begin[ej] = ej
+            end[ej] = ei_
+            end[bj] = ei_
+        else:
+            end[ei_] = bj
+            begin[bj] = bi
+            begin[ej] = bi
+            end[ej] = bj
+            end[bj] = bj
+        if cnt == n - 1:
+            break
+    fb, fe = _find(begin, 0), _find(end, 0)
+    A[fe, fb] = A[fb, fe] = 1
+    return A, it, completed
+
+
+def merge_tours(adj_mat, np_points, edge_index_np, sparse_graph=True, parallel_sampling=1):
+    """tsp_utils.py:89-145 (sparse branch :106-115, tour walk :131-141).  Returns (tours, mean merge_iterations,
+    completed flags)."""
+    assert sparse_graph
+    parts = np.split(np.asarray(adj_mat, dtype=np.float32).reshape(-1), parallel_sampling, axis=0)
+    n = np_points.shape[0]
+    tours, iters, done = [], [], []
+    for part in parts:
+        a = np.zeros((n, n), dtype=np.float32)
+        np.add.at(a, (edge_index_np[0], edge_index_np[1]), part)
+        dense = a + a.T                                  # float32 add, as scipy's toarray() + toarray()
+        real, it, ok = merge_dense(np_points, dense)
+        tour = [0]
+        while len(tour) < n + 1:
+            nb = np.nonzero(real[tour[-1]])[0]
+            if len(tour) > 1:
+                nb = nb[nb != tour[-2]]
+            tour.append(int(nb.max()))
+        tours.append(tour)
+        iters.append(it)
+        done.append(ok)
+    return tours, float(np.mean(iters)), done

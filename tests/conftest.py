@@ -16,3 +16,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+TESTS_DIR = os.path.dirname(os.path.abspath(__file__))
+if TESTS_DIR not in sys.path:          # test modules share helpers (e.g. test_gpu_decode imports test_decode_oracle)
+    sys.path.insert(0, TESTS_DIR)

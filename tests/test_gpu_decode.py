@@ -1,0 +1,103 @@
+"""Heatmap -> tour through the C ABI (difusco_tsp_merge_tour) on a real GPU: against the reference's fixtures,
+against the CPU oracle on seeded synthetic heatmaps, and size-independent properties at TSP-10000."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tsp_decode_oracle as D
+from test_decode_oracle import GOLDEN, check_against_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[11:-4] for p in GOLDEN])
+def test_merge_tours_matches_reference_fixture(dev, path):
+    from difusco_amd.decode import merge_tours
+    z = np.load(path)
+    par = int(z["parallel_sampling"])
+    tours, it_mean, done = merge_tours(z["heat"], z["points"], z["edge_index"], sparse_graph=True, parallel_sampling=par,
+                                       device=dev, return_completed=True)
+    iters = [merge_tours(part, z["points"], z["edge_index"], sparse_graph=True, device=dev)[1]
+             for part in np.split(z["heat"], par)]
+    check_against_fixture(z, tours, iters, done)
+    if z["completed"].all():
+        assert it_mean == float(z["merge_iterations"])
+
+
+def _heat(kind, pts, ei, rng):
+    d = np.linalg.norm(pts[ei[0]] - pts[ei[1]], axis=1)
+    if kind == "bits":
+        return ((rng.random(ei.shape[1]) < np.exp(-d / (0.6 * d.mean()))).astype(np.float32) + np.float32(1e-6))
+    if kind == "prob":
+        return (np.exp(-d / (0.5 * d.mean())) * rng.random(ei.shape[1])).astype(np.float32) + np.float32(1e-6)
+    return (rng.standard_normal(ei.shape[1]).astype(np.float32) * np.float32(0.25) + np.float32(0.75))
+
+
+@pytest.mark.parametrize("n,k,kind,shuffle", [(30, 29, "bits", False), (64, 63, "prob", True), (97, 96, "gauss", True),
+                                              (150, 15, "bits", True), (400, 40, "prob", False), (257, 31, "gauss", True),
+                                              (500, 50, "bits", False)])
+def test_merge_tours_matches_oracle(dev, n, k, kind, shuffle):
+    """Exact tour equality with the CPU oracle in BOTH regimes (the GPU path walks the zero block in the same stable
+    order as the oracle), with the edge list in arbitrary order."""
+    from difusco_amd.decode import merge_tours
+    from difusco_amd.synthetic import tsp_instance
+    rng = np.random.default_rng(n * 1000 + k)
+    pts, ei = tsp_instance(n, k, seed=n)
+    heat = _heat(kind, pts, ei, rng)
+    if shuffle:
+        perm = rng.permutation(ei.shape[1])
+        ei, heat = ei[:, perm], heat[perm]
+    ref_tours, ref_it, ref_done = D.merge_tours(heat, pts, ei, sparse_graph=True)
+    tours, it, done = merge_tours(heat, pts, ei, sparse_graph=True, device=dev, return_completed=True)
+    assert done == ref_done
+    assert tours == ref_tours
+    if done[0]:
+        assert it == ref_it
+
+
+def test_merge_tours_full_size_properties(dev):
+    """TSP-10000 / K=100 (10^6 heat entries; the reference would sort 10^8): a valid closed tour, bitwise
+    deterministic, invariant under a permutation of the edge list, and made of candidate edges wherever the
+    positive-score phase supplied them."""
+    from difusco_amd.decode import merge_tours
+    from difusco_amd.synthetic import tsp_instance
+    n, k = 10000, 100
+    pts, ei = tsp_instance(n, k, seed=3)
+    rng = np.random.default_rng(0)
+    heat = _heat("prob", pts, ei, rng)
+    t1, it1, d1 = merge_tours(heat, pts, ei, sparse_graph=True, device=dev, return_completed=True)
+    t2, it2, d2 = merge_tours(heat, pts, ei, sparse_graph=True, device=dev, return_completed=True)
+    assert t1 == t2 and it1 == it2
+    tour = t1[0]
+    assert len(tour) == n + 1 and tour[0] == 0 and tour[-1] == 0 and sorted(tour[:-1]) == list(range(n))
+    perm = rng.permutation(ei.shape[1])
+    t3, _, _ = merge_tours(heat[perm], pts, ei[:, perm], sparse_graph=True, device=dev, return_completed=True)
+    assert t3 == t1
+    cand = set(zip(np.minimum(ei[0], ei[1]).tolist(), np.maximum(ei[0], ei[1]).tolist()))
+    on_graph = sum((min(a, b), max(a, b)) in cand for a, b in zip(tour[:-1], tour[1:]))
+    print(f"TSP-10000 decode: {on_graph}/{n} tour edges are k-NN candidates, completed={d1[0]}, merge_iterations={it1:.0f}")
+    assert on_graph >= 0.98 * n
+
+
+def test_sample_then_decode(dev):
+    """Sampling loop + decode end to end on a small instance (pl_tsp_model.py:185-228 without 2-opt)."""
+    from difusco_amd import TSPModel
+    from difusco_amd.decode import merge_tours
+    from oracle import difusco_oracle as O
+    p = O.init_params(64, 2, 2, seed=0)
+    pts, ei = O.tsp_instance(60, 12, seed=1)
+    args = dict(diffusion_type="categorical", diffusion_schedule="linear", diffusion_steps=1000, sparse_factor=12,
+                n_layers=2, hidden_dim=64, inference_trick="ddim", inference_diffusion_steps=10, inference_schedule="cosine")
+    m = TSPModel(args, p, device=dev, seed=3)
+    heat = m.sample(torch.from_numpy(pts).to(dev), torch.from_numpy(ei).to(dev))
+    tours, it = merge_tours(heat, pts, ei, sparse_graph=True, device=dev)
+    assert sorted(tours[0][:-1]) == list(range(60)) and it > 0
