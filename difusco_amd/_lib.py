@@ -85,6 +85,8 @@ def lib():
     L.difusco_tsp_merge_workspace_bytes.argtypes = [i64, ctypes.POINTER(ctypes.c_size_t)]
     L.difusco_tsp_merge_tour.argtypes = [i32, i64, vp, vp, f32p, f32p, vp, ctypes.c_size_t, vp,
                                          ctypes.POINTER(i64), ctypes.POINTER(i32), vp]
+    L.difusco_tsp_two_opt_workspace_bytes.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_size_t)]
+    L.difusco_tsp_two_opt.argtypes = [i32, i32, vp, vp, i64, vp, ctypes.c_size_t, ctypes.POINTER(i64), vp]
     if L.difusco_abi_version() != ABI_VERSION:
         raise DifuscoHipError(f"ABI version mismatch: library {L.difusco_abi_version()} != binding {ABI_VERSION}")
     _lib = L

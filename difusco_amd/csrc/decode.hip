@@ -79,7 +79,7 @@ __global__ void pair_score_kernel(const unsigned long long* __restrict__ key, co
   }
   const double dx = (double)points[2 * lo] - (double)points[2 * hi];
   const double dy = (double)points[2 * lo + 1] - (double)points[2 * hi + 1];
-  const double dist = sqrt(dx * dx + dy * dy);
+  const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));   // np.linalg.norm: no fused multiply-add
   score[p] = (double)s / dist;
   pair[p] = ((unsigned long long)lo << 32) | (unsigned long long)hi;
   atomicAdd(&counters[0], 1u);

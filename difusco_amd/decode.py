@@ -55,3 +55,26 @@ def merge_tours(adj_mat, np_points, edge_index_np, sparse_graph=False, parallel_
         done.append(bool(ok.value))
     merge_iterations = float(np.mean(iters))
     return (tours, merge_iterations, done) if return_completed else (tours, merge_iterations)
+
+
+def batched_two_opt_torch(points, tour, max_iterations=1000, device="cuda:0"):
+    """Drop-in for ``batched_two_opt_torch`` of the reference (``difusco/utils/tsp_utils.py:12-49``): ``points``
+    float64 [N,2] numpy, ``tour`` int [B, N+1] numpy (closed tours over the same points); returns
+    ``(tour int64 numpy [B, N+1], iterator)``.  Runs ``difusco_tsp_two_opt``; GPU only."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.DifuscoHipError("batched_two_opt_torch of difusco_amd runs on the GPU only (no CPU fallback)")
+    L = _lib.lib()
+    pts = _dev(np.asarray(points, dtype=np.float64), torch.float64, device)
+    tours = _dev(np.asarray(tour), torch.int32, device)
+    if tours.dim() != 2 or tours.shape[1] != pts.shape[0] + 1:
+        raise ValueError("tour must be [batch, N + 1] over the N points")
+    n, batch = pts.shape[0], tours.shape[0]
+    nbytes = ctypes.c_size_t()
+    _lib.check(L.difusco_tsp_two_opt_workspace_bytes(n, batch, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+    it = ctypes.c_int64()
+    _lib.check(L.difusco_tsp_two_opt(n, batch, ctypes.c_void_p(pts.data_ptr()), ctypes.c_void_p(tours.data_ptr()),
+                                     int(max_iterations), ctypes.c_void_p(ws.data_ptr()), nbytes.value, ctypes.byref(it),
+                                     ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+    return tours.cpu().numpy().astype(np.int64), int(it.value)

@@ -225,6 +225,16 @@ int difusco_tsp_merge_tour(int n_nodes, int64_t n_edges, const int32_t* row, con
                            const float* points, void* workspace, size_t workspace_bytes, int32_t* tour_out,
                            int64_t* merge_iterations, int32_t* completed, void* stream);
 
+/* ---- batched 2-opt: difusco/utils/tsp_utils.py:12-49 (batched_two_opt_torch).  points: DEVICE
+ * float64 [n_nodes,2]; tours: DEVICE int32 [batch, n_nodes+1] closed tours, refined in place.  Every iteration
+ * finds, per tour, the move (i,j), j >= i+2, that minimises d(t_i,t_j) + d(t_i+1,t_j+1) - d(t_i,t_i+1) - d(t_j,t_j+1)
+ * (float64, the reference's operation order, first flat index on ties) and reverses tour[i+1..j]; it stops when the
+ * best change over the whole batch is >= -1e-6 or after max_iterations applied moves.  *iterations_out (HOST) =
+ * the reference's `iterator`.  Blocks until done. */
+int difusco_tsp_two_opt_workspace_bytes(int n_nodes, int batch, size_t* bytes);
+int difusco_tsp_two_opt(int n_nodes, int batch, const double* points, int32_t* tours, int64_t max_iterations,
+                        void* workspace, size_t workspace_bytes, int64_t* iterations_out, void* stream);
+
 /* ---- in-library profiler (bench.py): HIP events on the launch stream around every kernel launch of
  * difusco_denoise_step, summed per category.  Categories: 0 edge-row linear (rows = n_edges),
  * 1 node-row linear, 2 edge gate/aggregate, 3 head (GroupNorm+conv+posterior, 3 launches),

@@ -95,3 +95,37 @@ def merge_tours(adj_mat, np_points, edge_index_np, sparse_graph=True, parallel_s
         iters.append(it)
         done.append(ok)
     return tours, float(np.mean(iters)), done
+
+
+def batched_two_opt(points, tour, max_iterations=1000):
+    """tsp_utils.py:12-49 (``batched_two_opt_torch``) in numpy float64: the four N x N distance matrices, their
+    combination in the reference's order, triu(diagonal=2), one global min over the batch for the stopping test,
+    per-tour argmin (first occurrence on the flattened matrix) and segment reversal."""
+    pts = np.asarray(points, dtype=np.float64)
+    tour = np.array(tour, dtype=np.int64, copy=True)
+    n = len(pts)
+    iterator = 0
+    min_change = -1.0
+    while min_change < 0.0:
+        pi = pts[tour[:, :-1]]                                   # [B, N, 2]
+        pi1 = pts[tour[:, 1:]]
+
+        def dmat(a, b):
+            d = a[:, :, None, :] - b[:, None, :, :]
+            return np.sqrt((d ** 2).sum(-1))
+        a_ij, a_i1j1 = dmat(pi, pi), dmat(pi1, pi1)
+        d_i = np.sqrt(((pi - pi1) ** 2).sum(-1))                 # [B, N]
+        change = a_ij + a_i1j1 - d_i[:, :, None] - d_i[:, None, :]
+        valid = np.triu(change, k=2)
+        min_change = valid.min()
+        flat = valid.reshape(len(tour), -1).argmin(-1)
+        mi, mj = flat // n, flat % n
+        if min_change < -1e-6:
+            for b in range(len(tour)):
+                tour[b, mi[b] + 1:mj[b] + 1] = tour[b, mi[b] + 1:mj[b] + 1][::-1].copy()
+            iterator += 1
+        else:
+            break
+        if iterator >= max_iterations:
+            break
+    return tour, iterator

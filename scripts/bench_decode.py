@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Decode (heatmap -> tour) timing on the GPU box: difusco_amd.decode.merge_tours (GPU sorts + host bookkeeping) with
+the heat already on the device, beside the CPU oracle (dense N x N restatement of the reference's merge_tours +
+merge_cython) on a bounded sample.  Prints one JSON line.  The oracle is only the cpu_baseline here."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from difusco_amd.decode import merge_tours  # noqa: E402
+from difusco_amd.synthetic import tsp_instance  # noqa: E402
+
+dev = torch.device("cuda:0")
+out = {"metric": "tours decoded per second (one sample per call)", "unit": "tours/s", "data": "synthetic", "cases": []}
+for n, k, reps, cpu in ((1000, 100, 20, True), (10000, 100, 5, False)):
+    pts, ei = tsp_instance(n, k, seed=11)
+    rng = np.random.default_rng(n)
+    d = np.linalg.norm(pts[ei[0]] - pts[ei[1]], axis=1)
+    heat = (np.exp(-d / (0.5 * d.mean())) * rng.random(ei.shape[1])).astype(np.float32) + np.float32(1e-6)
+    heat_d, pts_d, ei_d = torch.from_numpy(heat).to(dev), torch.from_numpy(pts).to(dev), torch.from_numpy(ei).to(dev)
+    merge_tours(heat_d, pts_d, ei_d, sparse_graph=True, device=dev)           # warm-up (rocPRIM kernels, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tours, it, done = merge_tours(heat_d, pts_d, ei_d, sparse_graph=True, device=dev, return_completed=True)
+    dt = (time.perf_counter() - t0) / reps
+    case = {"workload": f"TSP-{n} K={k} ({ei.shape[1]} heat entries)", "ms_per_tour": 1e3 * dt, "value": 1.0 / dt,
+            "completed_within_candidates": bool(done[0]), "merge_iterations": it}
+    if cpu:
+        from oracle import tsp_decode_oracle as D
+        t0 = time.perf_counter()
+        ref_tours, _, _ = D.merge_tours(heat, pts, ei, sparse_graph=True)
+        dtc = time.perf_counter() - t0
+        case["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "tours/s", "cores": 1, "kind": "port",
+                                "sample": f"1 tour, dense {n}x{n} numpy argsort + Python bookkeeping ({dtc:.2f} s)"}
+        case["equals_cpu_oracle"] = bool(ref_tours == tours)
+    out["cases"].append(case)
+print(json.dumps(out))

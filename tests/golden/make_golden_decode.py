@@ -92,6 +92,29 @@ def main():
                             provenance="reference: tsp_utils.merge_tours + cython_merge.merge_cython (pyx compiled here)")
         print(name, "E", E, "merge_iterations", per, "negative-key entries", neg, "completed", completed)
 
+    # ---- 2-opt: the reference's batched_two_opt_torch (tsp_utils.py:12-49) on the CPU, float64 points ----------
+    two_opt_cases = [("n50_random", 50, 1, 1000, "random"), ("n120_merge_b3", 120, 3, 1000, "merge"),
+                     ("n200_cap5_b2", 200, 2, 5, "random"), ("n40_converged", 40, 1, 1000, "converged"),
+                     ("n300_merge", 300, 1, 1000, "merge")]
+    for name, n, batch, max_it, kind in two_opt_cases:
+        rng = np.random.default_rng(sum(map(ord, name)))
+        pts32, ei = tsp_instance(n, min(20, n - 1), seed=7 * n)
+        pts = pts32.astype(np.float64)
+        if kind == "merge":
+            heat = np.concatenate([heat_case("prob", ei.shape[1], rng, ei, pts32) for _ in range(batch)])
+            with np.errstate(all="ignore"):
+                tours0, _ = tu.merge_tours(heat, pts32, ei, sparse_graph=True, parallel_sampling=batch)
+            tours0 = np.asarray(tours0, dtype=np.int64)
+        else:
+            tours0 = np.stack([np.concatenate([[0], 1 + rng.permutation(n - 1), [0]]) for _ in range(batch)]).astype(np.int64)
+        if kind == "converged":
+            tours0, _ = tu.batched_two_opt_torch(pts, tours0, max_iterations=10000, device="cpu")
+        out, it = tu.batched_two_opt_torch(pts, tours0, max_iterations=max_it, device="cpu")
+        np.savez_compressed(os.path.join(HERE, f"tsp_twoopt_{name}.npz"), points=pts, tours_in=tours0.astype(np.int32),
+                            tours_out=np.asarray(out, dtype=np.int32), iterations=np.int64(it), max_iterations=np.int64(max_it),
+                            provenance="reference: tsp_utils.batched_two_opt_torch (torch CPU, float64)")
+        print(name, "2-opt iterations", it)
+
 
 if __name__ == "__main__":
     main()

@@ -66,3 +66,14 @@ def test_oracle_matches_reference_fixture(path):
 def test_fixtures_cover_both_regimes():
     flags = np.concatenate([np.load(p)["completed"] for p in GOLDEN])
     assert flags.any() and (~flags).any() and len(GOLDEN) >= 6
+
+
+TWO_OPT = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tsp_twoopt_*.npz")))
+
+
+@pytest.mark.parametrize("path", TWO_OPT, ids=[os.path.basename(p)[11:-4] for p in TWO_OPT])
+def test_two_opt_oracle_matches_reference_fixture(path):
+    z = np.load(path)
+    out, it = D.batched_two_opt(z["points"], z["tours_in"], max_iterations=int(z["max_iterations"]))
+    assert it == int(z["iterations"])
+    assert np.array_equal(out, z["tours_out"])

@@ -101,3 +101,55 @@ def test_sample_then_decode(dev):
     heat = m.sample(torch.from_numpy(pts).to(dev), torch.from_numpy(ei).to(dev))
     tours, it = merge_tours(heat, pts, ei, sparse_graph=True, device=dev)
     assert sorted(tours[0][:-1]) == list(range(60)) and it > 0
+
+
+# ---- 2-opt ---------------------------------------------------------------------------------------------------
+from test_decode_oracle import TWO_OPT  # noqa: E402
+
+
+def _tour_len(pts, tour):
+    return float(np.linalg.norm(pts[tour[:-1]] - pts[tour[1:]], axis=1).sum())
+
+
+@pytest.mark.parametrize("path", TWO_OPT, ids=[os.path.basename(p)[11:-4] for p in TWO_OPT])
+def test_two_opt_matches_reference_fixture(dev, path):
+    """Exact moves: same tours and same iteration counter as the reference's batched_two_opt_torch."""
+    from difusco_amd.decode import batched_two_opt_torch
+    z = np.load(path)
+    out, it = batched_two_opt_torch(z["points"], z["tours_in"], max_iterations=int(z["max_iterations"]), device=dev)
+    assert it == int(z["iterations"])
+    assert np.array_equal(out, z["tours_out"])
+
+
+@pytest.mark.parametrize("n,batch,max_it", [(33, 2, 1000), (257, 1, 1000), (500, 4, 40), (1000, 1, 25)])
+def test_two_opt_matches_oracle(dev, n, batch, max_it):
+    from difusco_amd.decode import batched_two_opt_torch
+    rng = np.random.default_rng(n + batch)
+    pts = rng.random((n, 2))
+    tours = np.stack([np.concatenate([[0], 1 + rng.permutation(n - 1), [0]]) for _ in range(batch)])
+    ref, ref_it = D.batched_two_opt(pts, tours, max_iterations=max_it)
+    out, it = batched_two_opt_torch(pts, tours, max_iterations=max_it, device=dev)
+    assert it == ref_it and np.array_equal(out, ref)
+
+
+def test_two_opt_full_size_properties(dev):
+    """TSP-10000 (the reference would hold four 10^8-entry float64 matrices per iteration): tours stay permutations,
+    every applied move shortens the tour, the run is bitwise deterministic, and a capped run is a prefix of a longer
+    one (same moves in the same order)."""
+    from difusco_amd.decode import batched_two_opt_torch
+    n = 10000
+    rng = np.random.default_rng(5)
+    pts = rng.random((n, 2))
+    order = np.argsort(pts[:, 0] // 0.05 * 10 + pts[:, 1] * (1 - 2 * ((pts[:, 0] // 0.05) % 2)))   # strip tour
+    order = np.roll(order, -int(np.where(order == 0)[0][0]))
+    tour0 = np.concatenate([order, [0]])[None, :]
+    a, it_a = batched_two_opt_torch(pts, tour0, max_iterations=30, device=dev)
+    b, it_b = batched_two_opt_torch(pts, tour0, max_iterations=30, device=dev)
+    assert it_a == it_b == 30 and np.array_equal(a, b)
+    assert sorted(a[0][:-1].tolist()) == list(range(n)) and a[0][0] == 0 and a[0][-1] == 0
+    c, it_c = batched_two_opt_torch(pts, tour0, max_iterations=10, device=dev)
+    d, it_d = batched_two_opt_torch(pts, c, max_iterations=20, device=dev)
+    assert it_c == 10 and it_d == 20 and np.array_equal(d, a)
+    l0, l10, l30 = _tour_len(pts, tour0[0]), _tour_len(pts, c[0]), _tour_len(pts, a[0])
+    print(f"TSP-10000 2-opt: length {l0:.3f} -> {l10:.3f} (10 moves) -> {l30:.3f} (30 moves)")
+    assert l30 < l10 < l0
