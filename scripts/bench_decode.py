@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from difusco_amd.decode import merge_tours  # noqa: E402
+from difusco_amd.decode import batched_two_opt_torch, merge_tours  # noqa: E402
 from difusco_amd.synthetic import tsp_instance  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -38,5 +38,23 @@ for n, k, reps, cpu in ((1000, 100, 20, True), (10000, 100, 5, False)):
         case["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "tours/s", "cores": 1, "kind": "port",
                                 "sample": f"1 tour, dense {n}x{n} numpy argsort + Python bookkeeping ({dtc:.2f} s)"}
         case["equals_cpu_oracle"] = bool(ref_tours == tours)
+    # 2-opt on the decoded tour (tsp_utils.py:12-49): time per applied move, float64
+    tour0 = np.asarray(tours, dtype=np.int64)
+    cap = 200 if n <= 1000 else 50
+    batched_two_opt_torch(pts.astype(np.float64), tour0, max_iterations=2, device=dev)       # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    refined, moves = batched_two_opt_torch(pts.astype(np.float64), tour0, max_iterations=cap, device=dev)
+    dt2 = time.perf_counter() - t0
+    length = lambda t: float(np.linalg.norm(pts[t[:-1]] - pts[t[1:]], axis=1).sum())
+    case["two_opt"] = {"moves": moves, "cap": cap, "ms_total": 1e3 * dt2, "ms_per_move": 1e3 * dt2 / max(moves, 1),
+                       "pairs_per_move": n * (n - 3) // 2, "tour_length_before": length(tour0[0]),
+                       "tour_length_after": length(refined[0])}
+    if cpu:
+        t0 = time.perf_counter()
+        ref_refined, ref_moves = D.batched_two_opt(pts.astype(np.float64), tour0, max_iterations=10)
+        dtc = time.perf_counter() - t0
+        case["two_opt"]["cpu_baseline"] = {"ms_per_move": 1e3 * dtc / max(ref_moves, 1), "cores": 1, "kind": "port",
+                                           "sample": f"{ref_moves} moves of the numpy restatement ({dtc:.2f} s)"}
     out["cases"].append(case)
 print(json.dumps(out))
