@@ -153,7 +153,7 @@ def main():
     from difusco_amd.engine import DenoiseEngine
     from difusco_amd.models import MISModel, TSPModel
     from difusco_amd.schedules import InferenceSchedule
-    from difusco_amd.synthetic import er_mis_edge_index, random_state_dict, tsp_batch
+    from difusco_amd.synthetic import er_mis_edge_index, random_state_dict, tsp_batch_gpu
 
     # frozen weights: rank 0 creates, RCCL broadcast of the packed blob over xGMI
     params = random_state_dict(H, LAYERS, 1 if gaussian else 2, seed=20240926) if rank == 0 or world == 1 else None
@@ -181,7 +181,7 @@ def main():
         N_local = n_off
         xt = (torch.randn(N_local, generator=gen) > 0).float().to(device)
     else:
-        points, edge_index = tsp_batch(args.nodes, args.knn, range(lo, hi), device)
+        points, edge_index = tsp_batch_gpu(args.nodes, args.knn, range(lo, hi), device)   # k-NN graphs built on the GPU
         N_local = points.shape[0]
         xt = torch.randn(edge_index.shape[1], generator=gen)
         xt = (xt if gaussian else (xt > 0).float()).to(device)

@@ -96,3 +96,29 @@ def to_tiled(e: torch.Tensor) -> torch.Tensor:
 def from_tiled(buf: torch.Tensor, n_edges: int) -> torch.Tensor:
     off = edge_tiled_offsets(n_edges).to(buf.device)
     return buf[off[:n_edges].reshape(-1)].reshape(n_edges, 256)
+
+
+def knn_edge_index_gpu(points, k: int, device="cuda:0", graphs: int = 1) -> torch.Tensor:
+    """``edge_index`` int64 [2, G*n*k] on ``device`` in the reference's layout (``co_datasets/tsp_graph_dataset.py:
+    53-62``; batch = disjoint union with node ids offset by g*n, ``pl_meta_model.py:177-184``), built by
+    ``difusco_knn_graph``.  ``points``: float64 [G*n, 2] (numpy or tensor), G graphs of n points each."""
+    import ctypes
+    L = _lib.lib()
+    device = torch.device(device)
+    if isinstance(points, np.ndarray):
+        points = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float64))
+    pts = points.to(device=device, dtype=torch.float64).contiguous()
+    n = pts.shape[0] // graphs
+    if n * graphs != pts.shape[0]:
+        raise ValueError("points must hold `graphs` instances of equal size")
+    ei = torch.empty((2, graphs * n * k), dtype=torch.int64, device=device)
+    nbytes = ctypes.c_size_t()
+    _lib.check(L.difusco_knn_graph_workspace_bytes(n, k, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    for g in range(graphs):
+        _lib.check(L.difusco_knn_graph(n, k, ctypes.c_void_p(pts[g * n:].data_ptr()), g * n,
+                                       ctypes.c_void_p(ei[0, g * n * k:].data_ptr()),
+                                       ctypes.c_void_p(ei[1, g * n * k:].data_ptr()),
+                                       ctypes.c_void_p(ws.data_ptr()), nbytes.value, stream))
+    return ei

@@ -40,6 +40,16 @@ def tsp_batch(n: int, k: int, graph_ids, device=None):
     return (points.to(device), edge_index.to(device)) if device is not None else (points, edge_index)
 
 
+def tsp_batch_gpu(n: int, k: int, graph_ids, device):
+    """Same instances as :func:`tsp_batch` (same seeds, same float32 coordinates), with the k-NN graphs built on the
+    GPU by ``difusco_knn_graph`` instead of the numpy brute force (identical edge_index, checked by the GPU tests)."""
+    from .graph import knn_edge_index_gpu
+    graph_ids = list(graph_ids)
+    pts64 = np.concatenate([np.random.default_rng(1000 + int(g)).random((n, 2)) for g in graph_ids], 0)
+    edge_index = knn_edge_index_gpu(pts64, k, device=device, graphs=len(graph_ids))
+    return torch.from_numpy(pts64.astype(np.float32)).to(device), edge_index
+
+
 def er_mis_edge_index(n: int, prob: float, seed: int) -> np.ndarray:
     """G(n,p) undirected edges + reversed copies + self loops, not row-sorted
     (``co_datasets/mis_dataset.py:43-48``)."""

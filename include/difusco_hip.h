@@ -210,6 +210,15 @@ int difusco_gaussian_posterior(const float* pred, const float* xt, const float* 
                                int rand_mode, const float* rand, uint64_t seed, uint64_t offset,
                                float* xt_out, int64_t n, void* stream);
 
+/* ---- k-NN graph in the reference's layout: co_datasets/tsp_graph_dataset.py:53-62
+ * (sklearn KDTree(points).query(points, k) on float64 coordinates).  points: DEVICE float64 [n_nodes,2]; writes
+ * edge_row0[i*k + r] = node_offset + i and edge_row1[i*k + r] = node_offset + (r-th nearest neighbour of i, self
+ * first, ties by lower index) - DEVICE int64, i.e. the graph's slice of a [2, E_tot] edge_index of a disjoint-union
+ * batch (pl_meta_model.py:177-184).  1 <= k <= min(n_nodes, 1024).  Asynchronous on `stream`. */
+int difusco_knn_graph_workspace_bytes(int n_nodes, int k, size_t* bytes);
+int difusco_knn_graph(int n_nodes, int k, const double* points, int64_t node_offset, int64_t* edge_row0,
+                      int64_t* edge_row1, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- heatmap -> tour: the greedy edge insertion the reference runs on the host right after the
  * sampling loop, difusco/utils/tsp_utils.py:89-145 (merge_tours) + utils/cython_merge/cython_merge.pyx:19-104
  * (merge_cython), restricted to the E entries of the sparse heatmap instead of the N x N densification.

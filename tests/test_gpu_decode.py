@@ -153,3 +153,47 @@ def test_two_opt_full_size_properties(dev):
     l0, l10, l30 = _tour_len(pts, tour0[0]), _tour_len(pts, c[0]), _tour_len(pts, a[0])
     print(f"TSP-10000 2-opt: length {l0:.3f} -> {l10:.3f} (10 moves) -> {l30:.3f} (30 moves)")
     assert l30 < l10 < l0
+
+
+# ---- k-NN graph construction -----------------------------------------------------------------------------------
+def test_knn_graph_matches_sklearn_fixture(dev, golden_dir):  # noqa: F811
+    import glob
+    from difusco_amd.graph import knn_edge_index_gpu
+    for p in sorted(glob.glob(os.path.join(golden_dir, "knn_*.npz"))):
+        z = np.load(p)
+        k, n = int(z["k"]), z["points"].shape[0]
+        ei = knn_edge_index_gpu(z["points"], k, device=dev).cpu().numpy()
+        assert np.array_equal(ei[0], np.repeat(np.arange(n), k))
+        assert np.array_equal(ei[1].reshape(n, k), z["idx_knn"]), p
+
+
+@pytest.mark.parametrize("n,k,graphs", [(1000, 100, 3), (10000, 100, 1), (17000, 8, 1), (5, 5, 2), (300, 1, 1)])
+def test_knn_graph_matches_host_generator(dev, n, k, graphs):
+    """Full sizes (TSP-1000 batch, TSP-10000, the global-scratch path above 16000 points) against the numpy brute
+    force, including the node-id offsets of a disjoint-union batch."""
+    from difusco_amd.graph import knn_edge_index_gpu
+    from difusco_amd.synthetic import knn_edge_index
+    pts = np.random.default_rng(n + k).random((graphs * n, 2))
+    ref = np.concatenate([knn_edge_index(pts[g * n:(g + 1) * n], k) + g * n for g in range(graphs)], axis=1)
+    ei = knn_edge_index_gpu(pts, k, device=dev, graphs=graphs).cpu().numpy()
+    assert np.array_equal(ei, ref)
+
+
+def test_knn_graph_ties_and_errors(dev):
+    from difusco_amd import _lib
+    from difusco_amd.graph import knn_edge_index_gpu
+    pts = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0], [0.5, 0.5], [0.5, 0.5]])   # duplicates + exact ties
+    ei = knn_edge_index_gpu(pts, 4, device=dev).cpu().numpy()[1].reshape(6, 4)
+    d = ((pts[:, None] - pts[None]) ** 2).sum(-1)
+    for i in range(6):
+        order = sorted(range(6), key=lambda j: (d[i, j], j))[:4]      # ties -> lower index
+        assert ei[i].tolist() == order
+    with pytest.raises(_lib.DifuscoHipError):
+        knn_edge_index_gpu(pts, 7, device=dev)
+
+
+def test_tsp_batch_gpu_equals_host_batch(dev):
+    from difusco_amd.synthetic import tsp_batch, tsp_batch_gpu
+    p0, e0 = tsp_batch(200, 20, range(3, 6))
+    p1, e1 = tsp_batch_gpu(200, 20, range(3, 6), dev)
+    assert torch.equal(p0, p1.cpu()) and torch.equal(e0, e1.cpu())

@@ -229,3 +229,19 @@ def test_split_planes_layout_and_exactness():
     assert torch.equal(bf[0], w.to(torch.bfloat16).float())
     assert torch.equal(fp[0], w.to(torch.float16).float())
     assert (fp.sum(0) - w).abs().max().item() <= 2 ** -21 * w.abs().max().item()     # 22 bits recovered
+
+
+def test_knn_generator_matches_sklearn_fixture(golden_dir):
+    """The host-side k-NN generator (difusco_amd/synthetic.py, used for synthetic inputs and as the checker of the
+    GPU k-NN kernel) against sklearn KDTree outputs (tests/golden/make_golden_knn.py)."""
+    import glob
+    from difusco_amd.synthetic import knn_edge_index
+    paths = sorted(glob.glob(os.path.join(golden_dir, "knn_*.npz")))
+    assert len(paths) >= 4
+    for p in paths:
+        z = np.load(p)
+        k = int(z["k"])
+        ei = knn_edge_index(z["points"], k)
+        n = z["points"].shape[0]
+        assert np.array_equal(ei[0], np.repeat(np.arange(n), k))
+        assert np.array_equal(ei[1].reshape(n, k), z["idx_knn"])
