@@ -89,6 +89,8 @@ def lib():
     L.difusco_tsp_two_opt.argtypes = [i32, i32, vp, vp, i64, vp, ctypes.c_size_t, ctypes.POINTER(i64), vp]
     L.difusco_knn_graph_workspace_bytes.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_size_t)]
     L.difusco_knn_graph.argtypes = [i32, i32, vp, i64, vp, vp, vp, ctypes.c_size_t, vp]
+    L.difusco_mis_decode_workspace_bytes.argtypes = [i32, ctypes.POINTER(ctypes.c_size_t)]
+    L.difusco_mis_decode.argtypes = [i32, vp, vp, f32p, vp, vp, ctypes.c_size_t, ctypes.POINTER(i32), vp]
     if L.difusco_abi_version() != ABI_VERSION:
         raise DifuscoHipError(f"ABI version mismatch: library {L.difusco_abi_version()} != binding {ABI_VERSION}")
     _lib = L

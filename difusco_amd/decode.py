@@ -78,3 +78,31 @@ def batched_two_opt_torch(points, tour, max_iterations=1000, device="cuda:0"):
                                      int(max_iterations), ctypes.c_void_p(ws.data_ptr()), nbytes.value, ctypes.byref(it),
                                      ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
     return tours.cpu().numpy().astype(np.int64), int(it.value)
+
+
+def mis_decode_np(predictions, adj_matrix=None, *, graph=None, edge_index=None, device="cuda:0"):
+    """Drop-in for ``mis_decode_np`` of the reference (``difusco/utils/mis_utils.py:3-18``): ``predictions`` [N] node
+    scores (numpy or tensor), ``adj_matrix`` a scipy sparse adjacency (as built at ``pl_mis_model.py:152-154``).
+    Returns the 0/1 int numpy array.  Instead of a scipy matrix the caller may pass the ``CsrGraph`` of the denoise
+    steps (``graph=``, no host round trip) or the ``edge_index`` the adjacency was built from.  GPU only."""
+    from .graph import build_csr
+    device = torch.device(device)
+    L = _lib.lib()
+    scores = _dev(predictions, torch.float32, device).reshape(-1)
+    n = scores.shape[0]
+    if graph is None:
+        if edge_index is None:
+            coo = adj_matrix.tocoo()
+            edge_index = np.stack([coo.row, coo.col]).astype(np.int64)
+        graph = build_csr(edge_index if isinstance(edge_index, torch.Tensor) else torch.from_numpy(np.asarray(edge_index)),
+                          n, device)
+    nbytes = ctypes.c_size_t()
+    _lib.check(L.difusco_mis_decode_workspace_bytes(n, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+    sol = torch.empty(n, dtype=torch.int32, device=device)
+    rounds = ctypes.c_int32()
+    _lib.check(L.difusco_mis_decode(n, ctypes.c_void_p(graph.rowptr.data_ptr()), ctypes.c_void_p(graph.col.data_ptr()),
+                                    ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(sol.data_ptr()),
+                                    ctypes.c_void_p(ws.data_ptr()), nbytes.value, ctypes.byref(rounds),
+                                    ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+    return sol.cpu().numpy().astype(int)

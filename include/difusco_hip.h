@@ -219,6 +219,15 @@ int difusco_knn_graph_workspace_bytes(int n_nodes, int k, size_t* bytes);
 int difusco_knn_graph(int n_nodes, int k, const double* points, int64_t node_offset, int64_t* edge_row0,
                       int64_t* edge_row1, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- greedy MIS decode: difusco/utils/mis_utils.py:3-18 (mis_decode_np).  rowptr/col: DEVICE CSR of
+ * the symmetric adjacency of the whole call (self loops allowed, as in co_datasets/mis_dataset.py:43-48; the
+ * graphs of a batch are independent components); scores: DEVICE float32 [n_nodes] (the final x_t, + 1e-6 or
+ * * 0.5 + 0.5 applied); solution: DEVICE int32 [n_nodes], 1 = in the independent set.  Visiting order = decreasing
+ * score, equal scores by increasing node id.  *rounds_out (HOST, optional) = parallel rounds used.  Blocks. */
+int difusco_mis_decode_workspace_bytes(int n_nodes, size_t* bytes);
+int difusco_mis_decode(int n_nodes, const int32_t* rowptr, const int32_t* col, const float* scores, int32_t* solution,
+                       void* workspace, size_t workspace_bytes, int32_t* rounds_out, void* stream);
+
 /* ---- heatmap -> tour: the greedy edge insertion the reference runs on the host right after the
  * sampling loop, difusco/utils/tsp_utils.py:89-145 (merge_tours) + utils/cython_merge/cython_merge.pyx:19-104
  * (merge_cython), restricted to the E entries of the sparse heatmap instead of the N x N densification.

@@ -129,3 +129,20 @@ def batched_two_opt(points, tour, max_iterations=1000):
         if iterator >= max_iterations:
             break
     return tour, iterator
+
+
+def mis_decode(predictions, edge_index, n_nodes):
+    """mis_utils.py:3-18 (``mis_decode_np``) with the adjacency given as the edge_index it is built from
+    (pl_mis_model.py:150-154); nodes are visited in decreasing score, equal scores by increasing id (the reference's
+    argsort is unstable there)."""
+    pred = np.asarray(predictions).reshape(-1)
+    nbrs = [[] for _ in range(n_nodes)]
+    for a, b in zip(edge_index[0].tolist(), edge_index[1].tolist()):
+        nbrs[a].append(b)
+    solution = np.zeros(n_nodes, dtype=int)
+    for i in np.argsort(-pred, kind="stable"):
+        if solution[i] == -1:
+            continue
+        solution[nbrs[i]] = -1
+        solution[i] = 1
+    return (solution == 1).astype(int)

@@ -116,5 +116,26 @@ def main():
         print(name, "2-opt iterations", it)
 
 
+def mis_fixtures():
+    """mis_decode_np of the reference (utils/mis_utils.py, imports unmodified) on Erdos-Renyi graphs in the dataset's
+    layout (both directions + self loops) with continuous, tie-free scores."""
+    import scipy.sparse
+    from difusco_amd.synthetic import er_mis_edge_index
+    spec = importlib.util.spec_from_file_location("ref_mis_utils", os.path.join(REF, "utils", "mis_utils.py"))
+    mu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mu)
+    for name, n, p, seed in [("n60_p15", 60, 0.15, 1), ("n300_p05", 300, 0.05, 2), ("n750_p15", 750, 0.15, 3)]:
+        ei = er_mis_edge_index(n, p, seed)
+        rng = np.random.default_rng(seed)
+        pred = (rng.random(n).astype(np.float32) + np.float32(1e-6))
+        adj = scipy.sparse.coo_matrix((np.ones_like(ei[0]), (ei[0], ei[1])))          # pl_mis_model.py:152-154
+        sol = mu.mis_decode_np(pred, adj)
+        assert len(np.unique(pred)) == n
+        np.savez_compressed(os.path.join(HERE, f"mis_decode_{name}.npz"), edge_index=ei.astype(np.int32), predictions=pred,
+                            solution=sol.astype(np.int8), provenance="reference: utils/mis_utils.mis_decode_np")
+        print(name, "set size", int(sol.sum()))
+
+
 if __name__ == "__main__":
+    mis_fixtures()
     main()

@@ -77,3 +77,14 @@ def test_two_opt_oracle_matches_reference_fixture(path):
     out, it = D.batched_two_opt(z["points"], z["tours_in"], max_iterations=int(z["max_iterations"]))
     assert it == int(z["iterations"])
     assert np.array_equal(out, z["tours_out"])
+
+
+MIS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "mis_decode_*.npz")))
+
+
+@pytest.mark.parametrize("path", MIS, ids=[os.path.basename(p)[11:-4] for p in MIS])
+def test_mis_decode_oracle_matches_reference_fixture(path):
+    z = np.load(path)
+    n = z["predictions"].shape[0]
+    sol = D.mis_decode(z["predictions"], z["edge_index"], n)
+    assert np.array_equal(sol, z["solution"].astype(int))

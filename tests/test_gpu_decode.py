@@ -197,3 +197,43 @@ def test_tsp_batch_gpu_equals_host_batch(dev):
     p0, e0 = tsp_batch(200, 20, range(3, 6))
     p1, e1 = tsp_batch_gpu(200, 20, range(3, 6), dev)
     assert torch.equal(p0, p1.cpu()) and torch.equal(e0, e1.cpu())
+
+
+# ---- MIS decode ------------------------------------------------------------------------------------------------
+from test_decode_oracle import MIS  # noqa: E402
+
+
+@pytest.mark.parametrize("path", MIS, ids=[os.path.basename(p)[11:-4] for p in MIS])
+def test_mis_decode_matches_reference_fixture(dev, path):
+    from difusco_amd.decode import mis_decode_np
+    z = np.load(path)
+    sol = mis_decode_np(z["predictions"], edge_index=z["edge_index"].astype(np.int64), device=dev)
+    assert np.array_equal(sol, z["solution"].astype(int))
+
+
+def test_mis_decode_batch_and_properties(dev):
+    """The per-GPU MIS shard of BASELINE (16 ER graphs, n in [700,800], one call): equals the oracle, is an
+    independent set, is maximal, handles score ties like a stable sort, accepts the scipy matrix of the reference."""
+    import scipy.sparse
+    from difusco_amd.decode import mis_decode_np
+    from difusco_amd.synthetic import er_mis_edge_index
+    eis, off = [], 0
+    for g in range(16):
+        n = int(np.random.default_rng(100 + g).integers(700, 801))
+        eis.append(er_mis_edge_index(n, 0.15, seed=g) + off)
+        off += n
+    ei = np.concatenate(eis, 1)
+    rng = np.random.default_rng(0)
+    pred = rng.random(off).astype(np.float32)
+    pred[rng.integers(0, off, 500)] = 0.5                      # exact ties
+    ref = D.mis_decode(pred, ei, off)
+    sol = mis_decode_np(pred, edge_index=ei, device=dev)
+    assert np.array_equal(sol, ref)
+    a, b = ei[0], ei[1]
+    nonself = a != b
+    assert not np.any((sol[a] == 1) & (sol[b] == 1) & nonself)          # independent
+    covered = np.zeros(off, dtype=bool)
+    covered[a[sol[b] == 1]] = True
+    assert np.all(covered | (sol == 1))                                   # maximal
+    adj = scipy.sparse.coo_matrix((np.ones_like(ei[0]), (ei[0], ei[1])))
+    assert np.array_equal(mis_decode_np(pred, adj, device=dev), ref)
