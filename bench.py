@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (0 = skip cpu_baseline)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-library HIP-event brackets")
     ap.add_argument("--no-fusion", action="store_true", help="unfused kernel sequence (A/B against the fused layer kernel)")
+    ap.add_argument("--no-l0-fold", action="store_true", help="A/B: write the first layer's edge input to HBM as a separate "
+                    "pass instead of reading it from the 2-row table inside the fused kernel")
     ap.add_argument("--precision", default="fp16x3", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
                     help="arithmetic of the E-row linears: exact fp32 MFMA, or fp32 split into 2/3 bf16 planes "
                          "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
@@ -149,6 +151,8 @@ def main():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from difusco_amd import _lib
+    if args.no_l0_fold:
+        _lib.check(_lib.lib().difusco_debug_set(3, 0))
     from difusco_amd.dist import GN_STATS_MODE, engine_from_broadcast, shard_range
     from difusco_amd.engine import DenoiseEngine
     from difusco_amd.models import MISModel, TSPModel

@@ -267,6 +267,10 @@ int difusco_denoise_step(const difusco_step_args* a) {
                      (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
   if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
   const int64_t E_pad = (E + 255) / 256 * 256;
+  // first layer: when the edge input is a table lookup (categorical TSP: embedding of the bit; MIS: zeros) the fused
+  // kernel takes it from the table and the pass that would write e0 to HBM is skipped
+  const bool l0_fold = fused && difusco::g_fused_l0_fold != 0 && difusco::g_fused_variant == 0 &&
+                       difusco::g_fused_ablate == 0 && (tsp ? a->xt_is_binary != 0 : true);
 
   // per-layer time bias rows: time_layer_l(time_embed(timestep_embedding(t)))   [L,H]
   PROF(PROF_EMBED, launch_time_bias(a->t, H, L, G(DIFUSCO_W_TIME_FREQS), G(DIFUSCO_W_TIME0_W), G(DIFUSCO_W_TIME0_B),
@@ -287,7 +291,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
       PROF(PROF_EMBED, launch_scalar_embed(nullptr, nullptr, G(DIFUSCO_W_DIMT_SCALAR), 2, H, ws.table_in, st))
       PROF(PROF_EMBED, linear_rows(ws.table_in, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.table,
                                    2, H, H, H, st))
-      if (fused) PROF(PROF_EMBED, launch_table_rows_tiled(a->xt, a->perm, ws.table, E, ws.e, st))
+      if (l0_fold) { /* e0 is read from ws.table by the first fused layer */ }
+      else if (fused) PROF(PROF_EMBED, launch_table_rows_tiled(a->xt, a->perm, ws.table, E, ws.e, st))
       else PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, ws.table, E, H, ws.e, st))
     } else {
       PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
@@ -305,7 +310,12 @@ int difusco_denoise_step(const difusco_step_args* a) {
     PROF(PROF_EMBED, launch_scalar_embed(a->xt, nullptr, G(DIFUSCO_W_DIMT_SCALAR), N, H, ws.node4, st))
     PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
                                        H, H, H, st))
-    if (E > 0) PROF(PROF_EMBED, hipMemsetAsync(ws.e, 0, sizeof(float) * (fused ? E_pad : E) * H, st))
+    if (l0_fold) {   // e = zeros (gnn_encoder.py:407) comes from an all-zero table; only the pad tail must read as zero
+      PROF(PROF_EMBED, hipMemsetAsync(ws.table, 0, sizeof(float) * 2 * H, st))
+      PROF(PROF_EMBED, hipMemsetAsync(ws.e + (E / 32) * 32 * H, 0, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
+    } else if (E > 0) {
+      PROF(PROF_EMBED, hipMemsetAsync(ws.e, 0, sizeof(float) * (fused ? E_pad : E) * H, st))
+    }
   }
 
   // the GNN layers (gnn_encoder.py:425-449)
@@ -320,7 +330,16 @@ int difusco_denoise_step(const difusco_step_args* a) {
       PROF(PROF_LINEAR_NODE, linear_rows(ws.h, LW(l, DIFUSCO_WL_NODE4_W), LW(l, DIFUSCO_WL_NODE4_B), nullptr, ws.node4,
                                          N, H, 4 * H, 4 * H, st))
     }
-    if (fused) {
+    if (fused && l == 0 && l0_fold) {
+      PROF(PROF_LINEAR_EDGE,
+           launch_edge_layer_fused_l0(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,
+                                      reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_C_PLANES)) + split_off,
+                                      reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_OUT_PLANES)) + split_off,
+                                      (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
+                                      LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
+                                      LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
+                                      ws.table, tsp ? a->xt : nullptr, tsp ? a->perm : nullptr, st))
+    } else if (fused) {
       PROF(PROF_LINEAR_EDGE,
            launch_edge_layer_fused(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,
                                    reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_C_PLANES)) + split_off,
@@ -329,6 +348,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                    LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                    LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
                                    st))
+    }
+    if (fused) {
       PROF(PROF_GATE, launch_node_finalize((int)N, (int)E, a->rowptr, ws.node4, ws.part, ws.direct, ws.h,
                                            LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
                                            ws.tbias + (size_t)l * H, tsp ? 1 : 0, st))
@@ -454,6 +475,7 @@ int difusco_debug_set_ptr(int key, void* p) {
 int difusco_debug_set(int key, int value) {
   if (key == 0) { difusco::g_fused_ablate = value; return DIFUSCO_OK; }
   if (key == 2) { difusco::g_fused_variant = value; return DIFUSCO_OK; }
+  if (key == 3) { difusco::g_fused_l0_fold = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }
 

@@ -38,7 +38,7 @@ namespace difusco {
 namespace fused {
 constexpr int H = 256;
 constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregation scratch (64 + 4 pad)
-enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT };
+enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT, P_TAB0, P_TAB1, P_COUNT };   // P_TAB*: layer-0 input table rows
 
 // Workgroup geometry.  NW waves = NW tiles of 32 edges.  A weight stage holds ENT rows of 32 bytes per plane:
 //   NW = 8: 512 rows (32 KiB / stage), 16 stages, ONE workgroup per CU: every weight byte fetched from L2 serves
@@ -58,20 +58,25 @@ struct Geo {
   static constexpr int SPQ = 16 / KPS;          // GEMM 2: stages per output quarter (2 | 4)
   static constexpr int NSTAGE = NS1 + 4 * SPQ;  // 16 | 32
   static constexpr int LDS_W = 2 * BUF * 2;     // bytes, double buffered             65536 | 32768
-  static constexpr int LDS_P = 7 * H * 4;       // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O     7168
+  static constexpr int LDS_P = P_COUNT * H * 4; // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O, table rows  9216
   static constexpr int LDS_S = NW * 32 * SCR_STRIDE * 4;   // bytes                   69632 | 34816
-  static constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;  // 142336 (1 WG/CU) | 74752 (2 WG/CU)
+  static constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;  // 144384 (1 WG/CU) | 76800 (2 WG/CU)
 };
 }  // namespace fused
 
-template <typename T, int ABL, int NW>
+template <typename T, int ABL, int NW, bool L0>
 __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
     float* e, const float* __restrict__ node4, const int* __restrict__ row, const int* __restrict__ col, int n_edges,
     const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
     const float* __restrict__ b_c, const float* __restrict__ g_e, const float* __restrict__ b_e,
     const float* __restrict__ tbias, const float* __restrict__ g_o, const float* __restrict__ b_o,
     const float* __restrict__ b_out, int time_on_edge, float* __restrict__ part, float* __restrict__ direct,
-    unsigned long long* dbg) {   // dbg: optional phase timestamps (profiling), nullptr in production
+    unsigned long long* dbg,     // dbg: optional phase timestamps (profiling), nullptr in production
+    const float* __restrict__ l0_table, const float* __restrict__ l0_x, const int* __restrict__ l0_perm) {
+  // L0 (first layer of a step whose edge input is a table lookup): e_in[s] = l0_table[x > 0.5 ? 1 : 0] with
+  // x = l0_x[l0_perm ? l0_perm[s] : s] (categorical TSP: the edge embedding of the bit x_t, gnn_encoder.py:395) or
+  // row 0 when l0_x is null (MIS: e = zeros, gnn_encoder.py:407).  The kernel then never reads e: the GEMM 1 operand
+  // and the residual come from the two table rows held in LDS, and the separate embedding pass over e disappears.
   // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
   // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
   constexpr int ablate = ABL;
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
         rs_e, (__attribute__((address_space(3))) void*)(scr + ((ks) & 1) * 512), 16, loff * 4, (ks) * 2048, 1024,       \
         0);                                                                                                  \
   }
-  if constexpr (kDmaE) {
+  if constexpr (L0) {
+    // no e stream
+  } else if constexpr (kDmaE) {
     FUSED_DMA_E(0)
     FUSED_DMA_E(1)
   } else {
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 #define FUSED_PIPE_END(t)                                                        \
   if ((t) + 1 < NSTAGE) {                                                        \
     if constexpr (kDma) {                                                        \
-      if (kDmaE && (t) + 2 < 16) __builtin_amdgcn_s_waitcnt(0x0F72); /* vmcnt(2) */ \
+      if (kDmaE && !L0 && (t) + 2 < 16) __builtin_amdgcn_s_waitcnt(0x0F72); /* vmcnt(2) */ \
       else __builtin_amdgcn_s_waitcnt(0x0F70);                       /* vmcnt(0) */ \
     }                                                                            \
     __syncthreads();                                                             \
@@ -259,6 +266,15 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
     prm[P_GO * H + tid] = g_o[tid];
     prm[P_BO * H + tid] = b_o[tid];
     prm[P_BOUT * H + tid] = b_out[tid];
+    if constexpr (L0) {
+      prm[P_TAB0 * H + tid] = l0_table[tid];
+      prm[P_TAB1 * H + tid] = l0_table[H + tid];
+    }
+  }
+  // layer 0: this lane's table row (float offset into prm), rule of table_rows_tiled_kernel
+  int l0_row = P_TAB0 * H;
+  if constexpr (L0) {
+    if (l0_x != nullptr && l0_x[l0_perm ? l0_perm[s] : s] > 0.5f) l0_row = P_TAB1 * H;
   }
   const int j = col[s];
   const int i_node = row[s];
@@ -292,7 +308,10 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
     for (int sub = 0; sub < SPS; ++sub) {
       const int ks = SPS * t + sub;
       v4f c0, c1;
-      if constexpr (kDmaE) {
+      if constexpr (L0) {
+        c0 = *reinterpret_cast<const v4f*>(prm + l0_row + 16 * ks + 4 * hh);
+        c1 = *reinterpret_cast<const v4f*>(prm + l0_row + 16 * ks + 8 + 4 * hh);
+      } else if constexpr (kDmaE) {
         c0 = *reinterpret_cast<const v4f*>(scr + (ks & 1) * 512 + loff);
         c1 = *reinterpret_cast<const v4f*>(scr + ((ks & 1) * 512 + 256) + loff);
       } else {
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       split8<T>(xs, xh[sub], xl[sub]);
-      if constexpr (kDmaE) {   // the slot is free once its values sit in registers: request slab ks + 2 into it
+      if constexpr (kDmaE && !L0) {   // the slot is free once its values sit in registers: request slab ks + 2 into it
         if (ks + 2 < 16) {
           __builtin_amdgcn_sched_barrier(0);
           FUSED_DMA_E(ks + 2)
@@ -513,8 +532,10 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 #pragma unroll
         for (int nbp = 0; nbp < 2; ++nbp)
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            ein[nbp][g] = *reinterpret_cast<const v4f*>(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff);
+          for (int g = 0; g < 4; ++g) {
+            if constexpr (L0) ein[nbp][g] = *reinterpret_cast<const v4f*>(prm + l0_row + 64 * qt + 32 * nbp + 8 * g + 4 * hh);
+            else ein[nbp][g] = *reinterpret_cast<const v4f*>(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff);
+          }
       }
       const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
       if constexpr (!skip_gemm2 && !skip_mm2) {
@@ -633,26 +654,27 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
 
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 int g_fused_ablate = 0;   // profiling knob (difusco_debug_set), 0 in production
+int g_fused_l0_fold = 1;  // 1: the first layer reads its edge input from the 2-row table (difusco_debug_set key 3)
 unsigned long long* g_fused_dbg = nullptr;   // profiling: device buffer for phase timestamps, [n_tiles][8]
 
-template <typename T, int ABL, int NW>
+template <typename T, int ABL, int NW, bool L0 = false>
 static hipError_t launch_fused_t(float* e, const float* node4, const int* row, const int* col, int n_edges,
                                  const unsigned short* c_planes, const unsigned short* o_planes, long long plane_stride,
                                  const float* b_c, const float* g_e, const float* b_e, const float* tbias,
                                  const float* g_o, const float* b_o, const float* b_out, int time_on_edge, float* part,
-                                 float* direct, hipStream_t stream) {
+                                 float* direct, hipStream_t stream, const float* l0_table = nullptr,
+                                 const float* l0_x = nullptr, const int* l0_perm = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW>),
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, fused::Geo<NW>::LDS_TOTAL);
     if (er != hipSuccess) return er;
     attr_set = true;
   }
   const unsigned grid = (unsigned)((n_edges + 32 * NW - 1) / (32 * NW));
-  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW>), dim3(grid), dim3(64 * NW), fused::Geo<NW>::LDS_TOTAL, stream, e,
-                     node4, row, col,
-                     n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, part,
-                     direct, g_fused_dbg);
+  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0>), dim3(grid), dim3(64 * NW), fused::Geo<NW>::LDS_TOTAL, stream,
+                     e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
+                     time_on_edge, part, direct, g_fused_dbg, l0_table, l0_x, l0_perm);
   return hipGetLastError();
 }
 
@@ -687,6 +709,27 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     default: return hipErrorInvalidValue;
   }
 #undef FUSED_ARGS
+}
+
+// First layer of a step whose edge input is a table lookup (see the L0 notes in the kernel): same as
+// launch_edge_layer_fused, but e is only written.  table: [2][256] floats, x: per caller-edge values (null = row 0),
+// perm: CSR slot -> caller edge id (null = identity).
+hipError_t launch_edge_layer_fused_l0(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
+                                      const unsigned short* c_planes, const unsigned short* o_planes,
+                                      long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
+                                      const float* tbias, const float* g_o, const float* b_o, const float* b_out,
+                                      int time_on_edge, float* part, float* direct, const float* table, const float* x,
+                                      const int* perm, hipStream_t stream) {
+  if (n_edges <= 0) return hipSuccess;
+  if (mode == 1)
+    return launch_fused_t<FBf16, 0, FUSED_NW, true>(e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e,
+                                                    b_e, tbias, g_o, b_o, b_out, time_on_edge, part, direct, stream, table,
+                                                    x, perm);
+  if (mode == 3)
+    return launch_fused_t<FFp16, 0, FUSED_NW, true>(e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e,
+                                                    b_e, tbias, g_o, b_o, b_out, time_on_edge, part, direct, stream, table,
+                                                    x, perm);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
