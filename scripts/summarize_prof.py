@@ -56,9 +56,15 @@ for counter, d in (("FETCH_SIZE", f"prof_fetch_{tag}"), ("WRITE_SIZE", f"prof_wr
         mb = raw * 1024 / 1e6 * (2.0 if counter == "FETCH_SIZE" else 1.0)
         print(f"{k:92s} {cnt[k]:8d} {raw:14.1f} {mb:14.1f}")
         short_key = k.split("(")[0].replace("void ", "").split("<")[0].strip()
-        traffic.setdefault(short_key, {"fetch_bytes": 0.0, "write_bytes": 0.0})
-        traffic[short_key]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = mb * 1e6
+        # template instantiations of one kernel share an entry: launch-weighted average
+        t = traffic.setdefault(short_key, {"fetch_bytes": 0.0, "write_bytes": 0.0, "_n": {}})
+        field = "fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"
+        n0 = t["_n"].get(field, 0)
+        t[field] = (t[field] * n0 + mb * 1e6 * cnt[k]) / (n0 + cnt[k])
+        t["_n"][field] = n0 + cnt[k]
     print("(MB_per_launch = raw * 1024 B" + (" * 2 (gfx950 FETCH_SIZE half-count correction)" if counter == "FETCH_SIZE" else " (uncalibrated)") + ")")
 
 import json
+for t in traffic.values():
+    t.pop("_n", None)
 json.dump(traffic, open(os.path.join(root, f"pmc_traffic_{tag}.json"), "w"), indent=1)
