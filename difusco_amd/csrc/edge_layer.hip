@@ -22,8 +22,10 @@
 // apart so that one's MFMA phases overlap the other's VALU / address-heavy epilogue) or NW = 8 (one per CU, half
 // the L2 weight traffic, phases in lock step) - see fused::Geo; 4 measured ~10 % faster.
 // Weights stream through LDS in stages of 64 NW rows of 32 bytes x 2 planes ([256 rows][16 k] slabs for GEMM 1,
-// [64 rows][16 k] sub-slabs of one output quarter for GEMM 2), double buffered, one barrier per stage; the rows are XOR-swizzled so every 16-lane group of ds_read_b128 hits 16
-// distinct 16-byte bank slots without padding.  GEMM 2 runs in four quarters of 64 output features (32
+// [64 rows][16 k] sub-slabs of one output quarter for GEMM 2), double buffered, filled by LDS-DMA
+// (buffer_load_dwordx4 ... lds, no staging registers), one barrier per stage; the rows are XOR-swizzled so every
+// 16-lane group of ds_read_b128 hits 16 distinct 16-byte bank slots without padding (the swizzle is applied to the
+// per-lane source address of the DMA, whose LDS side is lane-linear).  GEMM 2 runs in four quarters of 64 output features (32
 // accumulator registers) so that act planes (128) + accumulators + staging fit 256 VGPRs (2 waves/SIMD).
 //
 // Neighbour sum.  The gated messages m of a tile are transposed through a wave-private LDS scratch
@@ -31,6 +33,9 @@
 // the first or last of its tile may continue in the neighbouring tile: it goes to part[tile][0|1];
 // segments strictly inside a tile are complete and go to direct[node].  node_finalize_kernel adds the
 // pieces of each node in tile order - deterministic, no atomics.
+//
+// First layer (template flag L0): when the edge input is a lookup in a 2-row table (categorical TSP: the embedding
+// of the bit x_t; MIS: zeros) the table sits in LDS and the kernel never reads e - see the L0 notes at the kernel.
 #include "edge_layer_common.h"
 
 namespace difusco {
