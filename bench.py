@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--no-fusion", action="store_true", help="unfused kernel sequence (A/B against the fused layer kernel)")
     ap.add_argument("--no-l0-fold", action="store_true", help="A/B: write the first layer's edge input to HBM as a separate "
                     "pass instead of reading it from the 2-row table inside the fused kernel")
+    ap.add_argument("--no-gn-fold", action="store_true", help="A/B: head GroupNorm statistics by a separate pass over e "
+                    "instead of per-tile partial sums emitted by the last fused layer")
     ap.add_argument("--precision", default="fp16x3", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
                     help="arithmetic of the E-row linears: exact fp32 MFMA, or fp32 split into 2/3 bf16 planes "
                          "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
@@ -153,6 +155,8 @@ def main():
     from difusco_amd import _lib
     if args.no_l0_fold:
         _lib.check(_lib.lib().difusco_debug_set(3, 0))
+    if args.no_gn_fold:
+        _lib.check(_lib.lib().difusco_debug_set(4, 0))
     from difusco_amd.dist import GN_STATS_MODE, engine_from_broadcast, shard_range
     from difusco_amd.engine import DenoiseEngine
     from difusco_amd.models import MISModel, TSPModel

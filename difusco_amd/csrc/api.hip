@@ -88,7 +88,7 @@ Layout make_layout(int H, int L, int C) {
 }
 
 struct Workspace {
-  float *h, *node4, *e, *tmp, *tbias, *table_in, *table, *stats, *part, *direct;
+  float *h, *node4, *e, *tmp, *tbias, *table_in, *table, *stats, *part, *direct, *gn_tile;
   double* partial;
   size_t bytes;
 };
@@ -112,9 +112,10 @@ Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk)
   w.table_in = (float*)take(sizeof(float) * 2 * H);
   w.table = (float*)take(sizeof(float) * 2 * H);
   w.stats = (float*)take(sizeof(float) * S * 64);
-  w.partial = (double*)take(sizeof(double) * (size_t)S * (nblk < 8 ? 8 : nblk) * 64);
+  w.partial = (double*)take(sizeof(double) * (size_t)S * (nblk < 64 ? 64 : nblk) * 64);
   w.part = (float*)take(H == 256 ? sizeof(float) * fused_part_floats(E) : 0);
   w.direct = (float*)take(H == 256 ? sizeof(float) * N * H : 0);
+  w.gn_tile = (float*)take(H == 256 ? sizeof(float) * ((E + 255) / 256 * 8) * 64 : 0);   // per 32-edge tile: 32 x (sum, sumsq)
   w.bytes = cur;
   return w;
 }
@@ -269,6 +270,9 @@ int difusco_denoise_step(const difusco_step_args* a) {
   const int64_t E_pad = (E + 255) / 256 * 256;
   // first layer: when the edge input is a table lookup (categorical TSP: embedding of the bit; MIS: zeros) the fused
   // kernel takes it from the table and the pass that would write e0 to HBM is skipped
+  // last layer (TSP, at least two layers): the fused kernel also emits the head's GroupNorm partial sums per tile
+  const bool gn_fold = fused && tsp && L >= 2 && difusco::g_fused_gn_fold != 0 && difusco::g_fused_variant == 0 &&
+                       difusco::g_fused_ablate == 0;
   const bool l0_fold = fused && difusco::g_fused_l0_fold != 0 && difusco::g_fused_variant == 0 &&
                        difusco::g_fused_ablate == 0 && (tsp ? a->xt_is_binary != 0 : true);
 
@@ -339,6 +343,15 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                       LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                       LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
                                       ws.table, tsp ? a->xt : nullptr, tsp ? a->perm : nullptr, st))
+    } else if (fused && gn_fold && l == L - 1) {
+      PROF(PROF_LINEAR_EDGE,
+           launch_edge_layer_fused_gn(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,
+                                      reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_C_PLANES)) + split_off,
+                                      reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_OUT_PLANES)) + split_off,
+                                      (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
+                                      LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
+                                      LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
+                                      ws.gn_tile, st))
     } else if (fused) {
       PROF(PROF_LINEAR_EDGE,
            launch_edge_layer_fused(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,
@@ -371,7 +384,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
     PROF(PROF_HEAD, launch_head_tiled(C, ws.e, E, gn_blocks_for(out_rows) < 8 ? 8 : gn_blocks_for(out_rows) / 8 * 8,
                                       ws.partial, ws.stats, G(DIFUSCO_W_OUT_GN_W), G(DIFUSCO_W_OUT_GN_B),
                                       G(DIFUSCO_W_OUT_CONV_W), G(DIFUSCO_W_OUT_CONV_B), a->perm, a->xt, a->post,
-                                      a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st))
+                                      a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st,
+                                      gn_fold ? ws.gn_tile : nullptr))
     return DIFUSCO_OK;
   }
   PROF(PROF_HEAD, launch_head(H, C, tsp ? ws.e : ws.h, a->n_segments > 1 ? a->seg_ptr : nullptr, a->n_segments, out_rows,
@@ -476,6 +490,7 @@ int difusco_debug_set(int key, int value) {
   if (key == 0) { difusco::g_fused_ablate = value; return DIFUSCO_OK; }
   if (key == 2) { difusco::g_fused_variant = value; return DIFUSCO_OK; }
   if (key == 3) { difusco::g_fused_l0_fold = value; return DIFUSCO_OK; }
+  if (key == 4) { difusco::g_fused_gn_fold = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }
 

@@ -69,7 +69,7 @@ struct Geo {
 };
 }  // namespace fused
 
-template <typename T, int ABL, int NW, bool L0>
+template <typename T, int ABL, int NW, bool L0, bool GNP>
 __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
     float* e, const float* __restrict__ node4, const int* __restrict__ row, const int* __restrict__ col, int n_edges,
     const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
@@ -77,7 +77,11 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
     const float* __restrict__ tbias, const float* __restrict__ g_o, const float* __restrict__ b_o,
     const float* __restrict__ b_out, int time_on_edge, float* __restrict__ part, float* __restrict__ direct,
     unsigned long long* dbg,     // dbg: optional phase timestamps (profiling), nullptr in production
-    const float* __restrict__ l0_table, const float* __restrict__ l0_x, const int* __restrict__ l0_perm) {
+    const float* __restrict__ l0_table, const float* __restrict__ l0_x, const int* __restrict__ l0_perm,
+    float* __restrict__ gn_tile) {
+  // GNP (last layer of a step whose head reads e): per tile and GroupNorm group (8 channels = the two lane halves of
+  // one (quarter, block, quad)), the sum and the sum of squares of the NEW e values go to gn_tile[tile][32][2]; the
+  // head then needs no statistics pass over e (nn.py:93-100, gnn_encoder.py:400-401).
   // L0 (first layer of a step whose edge input is a table lookup): e_in[s] = l0_table[x > 0.5 ? 1 : 0] with
   // x = l0_x[l0_perm ? l0_perm[s] : s] (categorical TSP: the edge embedding of the bit x_t, gnn_encoder.py:395) or
   // row 0 when l0_x is null (MIS: e = zeros, gnn_encoder.py:407).  The kernel then never reads e: the GEMM 1 operand
@@ -574,6 +578,9 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 #pragma unroll
       for (int nbp = 0; nbp < 2; ++nbp) asm volatile("" ::"v"(acc2[nbp]));   // keep the MFMAs alive
     }
+    float gs[8], gq[8];      // GNP: this lane's share of the 8 groups of the quarter
+#pragma unroll
+    for (int u = 0; u < 8; ++u) gs[u] = gq[u] = 0.0f;
     if (valid && !skip_gemm2 && !skip_out) {
 #pragma unroll
       for (int nbp = 0; nbp < 2; ++nbp)
@@ -585,7 +592,20 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
           *reinterpret_cast<v4f*>(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff) = v;
+          if constexpr (GNP) {
+            gs[nbp * 4 + g] = (v[0] + v[1]) + (v[2] + v[3]);
+            gq[nbp * 4 + g] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          }
         }
+    }
+    if constexpr (GNP) {     // all lanes again: 16 wave sums, lane 0 writes the quarter's 8 (sum, sum of squares) pairs
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wave_sum2(gs[u], gq[u]);
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; u += 2)
+          *reinterpret_cast<v4f*>(gn_tile + (long long)tile * 64 + qt * 16 + 2 * u) = v4f{gs[u], gq[u], gs[u + 1], gq[u + 1]};
+      }
     }
     if (qt == 0) { FUSED_STAMP(8) }
   }
@@ -659,27 +679,28 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
 
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 int g_fused_ablate = 0;   // profiling knob (difusco_debug_set), 0 in production
+int g_fused_gn_fold = 1;  // 1: the last layer emits the head's GroupNorm partial sums (difusco_debug_set key 4)
 int g_fused_l0_fold = 1;  // 1: the first layer reads its edge input from the 2-row table (difusco_debug_set key 3)
 unsigned long long* g_fused_dbg = nullptr;   // profiling: device buffer for phase timestamps, [n_tiles][8]
 
-template <typename T, int ABL, int NW, bool L0 = false>
+template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false>
 static hipError_t launch_fused_t(float* e, const float* node4, const int* row, const int* col, int n_edges,
                                  const unsigned short* c_planes, const unsigned short* o_planes, long long plane_stride,
                                  const float* b_c, const float* g_e, const float* b_e, const float* tbias,
                                  const float* g_o, const float* b_o, const float* b_out, int time_on_edge, float* part,
                                  float* direct, hipStream_t stream, const float* l0_table = nullptr,
-                                 const float* l0_x = nullptr, const int* l0_perm = nullptr) {
+                                 const float* l0_x = nullptr, const int* l0_perm = nullptr, float* gn_tile = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0>),
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0, GNP>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, fused::Geo<NW>::LDS_TOTAL);
     if (er != hipSuccess) return er;
     attr_set = true;
   }
   const unsigned grid = (unsigned)((n_edges + 32 * NW - 1) / (32 * NW));
-  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0>), dim3(grid), dim3(64 * NW), fused::Geo<NW>::LDS_TOTAL, stream,
+  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP>), dim3(grid), dim3(64 * NW), fused::Geo<NW>::LDS_TOTAL, stream,
                      e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
-                     time_on_edge, part, direct, g_fused_dbg, l0_table, l0_x, l0_perm);
+                     time_on_edge, part, direct, g_fused_dbg, l0_table, l0_x, l0_perm, gn_tile);
   return hipGetLastError();
 }
 
@@ -714,6 +735,25 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     default: return hipErrorInvalidValue;
   }
 #undef FUSED_ARGS
+}
+
+// Last layer of a step whose head normalises e (TSP): as launch_edge_layer_fused, plus the per-tile GroupNorm partial
+// sums gn_tile[ceil(n_edges / 32)][32][2] of the new edge state (see the GNP notes in the kernel).
+hipError_t launch_edge_layer_fused_gn(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
+                                      const unsigned short* c_planes, const unsigned short* o_planes,
+                                      long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
+                                      const float* tbias, const float* g_o, const float* b_o, const float* b_out,
+                                      int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream) {
+  if (n_edges <= 0) return hipSuccess;
+  if (mode == 1)
+    return launch_fused_t<FBf16, 0, FUSED_NW, false, true>(e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c,
+                                                           g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, part, direct, stream,
+                                                           nullptr, nullptr, nullptr, gn_tile);
+  if (mode == 3)
+    return launch_fused_t<FFp16, 0, FUSED_NW, false, true>(e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c,
+                                                           g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, part, direct, stream,
+                                                           nullptr, nullptr, nullptr, gn_tile);
+  return hipErrorInvalidValue;
 }
 
 // First layer of a step whose edge input is a table lookup (see the L0 notes in the kernel): same as

@@ -466,6 +466,19 @@ __global__ __launch_bounds__(256) void gn_partial_tiled_kernel(const float* __re
   }
 }
 
+// GroupNorm partial sums that the last fused edge layer left per tile (gn_tile[tile][32 groups][sum, sumsq] floats)
+// -> partial[64 blocks][64] doubles in the all-groups-per-block layout of gn_finalize_kernel (group stride 1).
+__global__ __launch_bounds__(256) void gn_tiles_reduce_kernel(const float* __restrict__ gn_tile, long long n_tiles,
+                                                              double* __restrict__ partial) {
+  __shared__ double red[4][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (long long t = (long long)blockIdx.x * 4 + r; t < n_tiles; t += (long long)gridDim.x * 4) acc += (double)gn_tile[t * 64 + c];
+  red[r][c] = acc;
+  __syncthreads();
+  if (r == 0) partial[(long long)blockIdx.x * 64 + c] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+}
+
 // head on the tiled buffer: one wavefront per 32-edge tile; lane (l31, hh) accumulates the conv dot products of
 // edge l31 over its half of the channels, one cross-half exchange, then 32 lanes finish 32 edges at once.
 template <int C>
@@ -655,15 +668,20 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
                              const float* gn_w, const float* gn_b, const float* conv_w, const float* conv_b,
                              const int* perm, const float* xt, const float* post, int rand_mode, const float* rand,
                              unsigned long long seed, unsigned long long offset, float* xt_out, float* pred_out,
-                             float* prob_out, hipStream_t stream) {
+                             float* prob_out, hipStream_t stream, const float* gn_tile) {
   if (rows == 0) return hipSuccess;
-  if (nblk < 8 || nblk % 8 != 0) return hipErrorInvalidValue;
+  if (nblk < 8 || nblk % 8 != 0) return hipErrorInvalidValue;   // (with gn_tile, partial must hold 64 * 64 doubles)
   PostParams pp;
   for (int i = 0; i < 8; ++i) pp.p[i] = post[i];
   pp.rand_mode = rand_mode; pp.rand = rand; pp.seed = seed; pp.offset = offset;
   const long long n_tiles = (rows + 31) / 32;
-  hipLaunchKernelGGL(gn_partial_tiled_kernel, dim3(nblk), dim3(256), 0, stream, feat, n_tiles, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, nblk, 8, 8, stats);
+  if (gn_tile) {   // statistics come from the last fused layer: no pass over feat
+    hipLaunchKernelGGL(gn_tiles_reduce_kernel, dim3(64), dim3(256), 0, stream, gn_tile, n_tiles, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, 64, 8, 1, stats);
+  } else {
+    hipLaunchKernelGGL(gn_partial_tiled_kernel, dim3(nblk), dim3(256), 0, stream, feat, n_tiles, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, nblk, 8, 8, stats);
+  }
   long long blocks = (n_tiles + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   if (C == 2) {

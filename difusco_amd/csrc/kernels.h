@@ -37,6 +37,12 @@ hipError_t launch_edge_layer_fused_l0(int mode, float* e, const float* node4, co
                                       int time_on_edge, float* part, float* direct, const float* table, const float* x,
                                       const int* perm, hipStream_t stream);
 extern int g_fused_l0_fold;
+hipError_t launch_edge_layer_fused_gn(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
+                                      const unsigned short* c_planes, const unsigned short* o_planes,
+                                      long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
+                                      const float* tbias, const float* g_o, const float* b_o, const float* b_out,
+                                      int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream);
+extern int g_fused_gn_fold;
 // software-pipelined persistent variant of the same layer (edge_layer_pipe.hip); same arguments and results
 hipError_t launch_edge_layer_pipe(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
                                   const unsigned short* c_planes, const unsigned short* o_planes,
@@ -63,7 +69,7 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
                              const float* gn_w, const float* gn_b, const float* conv_w, const float* conv_b,
                              const int* perm, const float* xt, const float* post, int rand_mode, const float* rand,
                              unsigned long long seed, unsigned long long offset, float* xt_out, float* pred_out,
-                             float* prob_out, hipStream_t stream);
+                             float* prob_out, hipStream_t stream, const float* gn_tile = nullptr);
 hipError_t launch_edge_gate_aggregate(int H, int n_nodes, const int* rowptr, const int* col, const float* node4,
                                       float* ce_act, float* h, const float* nh_w, const float* nh_b, const float* ne_w,
                                       const float* ne_b, const float* ol_w, const float* ol_b, const float* tbias,
