@@ -45,32 +45,45 @@ constexpr int H = 256;
 constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregation scratch (64 + 4 pad)
 enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT, P_TAB0, P_TAB1, P_COUNT };   // P_TAB*: layer-0 input table rows
 
-// Workgroup geometry.  NW waves = NW tiles of 32 edges.  A weight stage holds ENT rows of 32 bytes per plane:
-//   NW = 8: 512 rows (32 KiB / stage), 16 stages, ONE workgroup per CU: every weight byte fetched from L2 serves
-//           256 edges, but all 8 waves walk the phases (GEMM 1, epilogue, GEMM 2) in lock step;
-//   NW = 4: 256 rows (16 KiB / stage), 32 stages, TWO workgroups per CU that drift apart, so one workgroup's
-//           MFMA phases overlap the other's VALU / address-unit heavy epilogue (at twice the L2 weight traffic).
-template <int NW>
+// Workgroup geometry (template parameter NW of the kernel is a geometry code).  A workgroup is WAVES tiles of 32
+// edges; a weight stage holds ENT rows of 32 bytes per plane:
+//   code 8 : 8 waves, 512 rows (32 KiB / stage), 16 stages, ONE workgroup per CU: every weight byte fetched from L2
+//            serves 256 edges, but all 8 waves walk the phases (GEMM 1, epilogue, GEMM 2) in lock step;
+//   code 4 : 4 waves, 256 rows (16 KiB / stage), 32 stages, TWO workgroups per CU that drift apart, so one
+//            workgroup's MFMA phases overlap the other's VALU / address-unit heavy epilogue;
+//   code 40: 4 waves, 512 rows (32 KiB / stage), 16 stages, two workgroups per CU: half the barriers of code 4.
+//            The 2 x 32 KiB of stage buffers only fit beside the aggregation scratch because the scratch ALIASES
+//            stage buffer 1 (+ 2 KiB): the scratch is used between the GEMMs only, the last GEMM 1 stage is the last
+//            reader of buffer 1 (barrier), and the first refill of buffer 1 in GEMM 2 waits for a barrier after the
+//            epilogue.  Measured: barriers + stage refills cost 0.09 ms per GEMM phase with 16 KiB stages.
+template <int CODE>
 struct Geo {
-  static constexpr int WAVES = NW;
-  static constexpr int THREADS = 64 * NW;
-  static constexpr int ENT = 64 * NW;           // entries (32-byte rows) per plane per stage
+  static constexpr bool ALIAS = CODE == 40;
+  static constexpr int WAVES = CODE == 8 ? 8 : 4;
+  static constexpr int THREADS = 64 * WAVES;
+  static constexpr int ENT = CODE == 4 ? 256 : 512;   // entries (32-byte rows) per plane per stage
+  static constexpr int PP = ENT / 32 / WAVES;      // 1 KiB LDS-DMA pieces per wave, plane and stage (2 | 2 | 4)
   static constexpr int PLANE = ENT * 16;        // 16-bit elements per plane per stage
   static constexpr int BUF = 2 * PLANE;         // one stage buffer: 2 planes
-  static constexpr int SPS = ENT / 256;         // GEMM 1: slabs per stage (2 | 1)
-  static constexpr int NS1 = 16 / SPS;          // GEMM 1 stages (8 | 16)
-  static constexpr int KPS = ENT / 64;          // GEMM 2: k slabs per stage (8 | 4)
-  static constexpr int SPQ = 16 / KPS;          // GEMM 2: stages per output quarter (2 | 4)
-  static constexpr int NSTAGE = NS1 + 4 * SPQ;  // 16 | 32
-  static constexpr int LDS_W = 2 * BUF * 2;     // bytes, double buffered             65536 | 32768
+  static constexpr int SPS = ENT / 256;         // GEMM 1: slabs per stage
+  static constexpr int NS1 = 16 / SPS;          // GEMM 1 stages
+  static constexpr int KPS = ENT / 64;          // GEMM 2: k slabs per stage
+  static constexpr int SPQ = 16 / KPS;          // GEMM 2: stages per output quarter
+  static constexpr int NSTAGE = NS1 + 4 * SPQ;  // 16 | 32 | 16
+  static constexpr int LDS_W = 2 * BUF * 2;     // bytes, double buffered             65536 | 32768 | 65536
   static constexpr int LDS_P = P_COUNT * H * 4; // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O, table rows  9216
-  static constexpr int LDS_S = NW * 32 * SCR_STRIDE * 4;   // bytes                   69632 | 34816
-  static constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;  // 144384 (1 WG/CU) | 76800 (2 WG/CU)
+  static constexpr int LDS_S = WAVES * 32 * SCR_STRIDE * 4;   // bytes                69632 | 34816 | 34816
+  // ALIAS: [buffer 0][buffer 1 = scratch ...][... scratch tail][parameters]; else [buffers][parameters][scratch]
+  static constexpr int OFF_S = ALIAS ? BUF * 2 : LDS_W + LDS_P;
+  static constexpr int OFF_P = ALIAS ? BUF * 2 + LDS_S : LDS_W;
+  static constexpr int LDS_TOTAL = ALIAS ? BUF * 2 + LDS_S + LDS_P : LDS_W + LDS_P + LDS_S;   // 144384 | 76800 | 76800
+  static_assert(!ALIAS || LDS_S >= BUF * 2, "the aliased scratch must cover stage buffer 1");
 };
+constexpr int geo_waves(int code) { return code == 8 ? 8 : 4; }
 }  // namespace fused
 
 template <typename T, int ABL, int NW, bool L0, bool GNP>
-__global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
+__global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused_kernel(
     float* e, const float* __restrict__ node4, const int* __restrict__ row, const int* __restrict__ col, int n_edges,
     const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
     const float* __restrict__ b_c, const float* __restrict__ g_e, const float* __restrict__ b_e,
@@ -92,12 +105,12 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   using namespace fused;
   typedef Geo<NW> G_;
   constexpr int WAVES = G_::WAVES, PLANE = G_::PLANE, BUF = G_::BUF, NSTAGE = G_::NSTAGE, SPS = G_::SPS, NS1 = G_::NS1,
-                KPS = G_::KPS, SPQ = G_::SPQ, LDS_W = G_::LDS_W, LDS_P = G_::LDS_P;
+                KPS = G_::KPS, SPQ = G_::SPQ, PP = G_::PP;
   typedef typename T::frag frag;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned short* wbuf = reinterpret_cast<unsigned short*>(smem_raw);
-  float* prm = reinterpret_cast<float*>(smem_raw + LDS_W);
-  float* scr_all = reinterpret_cast<float*>(smem_raw + LDS_W + LDS_P);
+  float* prm = reinterpret_cast<float*>(smem_raw + G_::OFF_P);
+  float* scr_all = reinterpret_cast<float*>(smem_raw + G_::OFF_S);
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,7 +150,10 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   //    FUSED_PIPE_END), each lane reads its own 16 bytes back.  Measured 2.5 % slower than the register ring
   //    (0.942 vs 0.919 ms per layer): the extra LDS round trip costs more than the 16 registers it frees.
   constexpr bool kDma = (ABL & 2048) == 0;                          // weight stages by LDS-DMA (else registers)
+  // profiling only (wrong results): matrix phases without stage refills and barriers / without the e stream
+  constexpr bool kNoSync = (ABL & 16384) != 0, kNoE = (ABL & 32768) != 0;
   constexpr bool kDmaE = kDma && SPS == 1 && (ABL & 4096) != 0;     // e stream by LDS-DMA too (experiment)
+  static_assert(kDma || !G_::ALIAS, "geometry 40 has no register-staged variant");
   constexpr int RING = kDma ? 2 : 4;   // beside LDS-DMA staging every load is drained at the stage barrier
   v4f er[RING][2];
   // (buffer addressing: SGPR resource + 32-bit lane offset + SGPR/immediate offsets - no per-lane 64-bit pointers;
@@ -220,28 +236,33 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   // multiplies stage t, then waits for its own requests (vmcnt(0)) before the barrier.
   unsigned dvoff1 = 0, dvoff2 = 0;
   if constexpr (kDma) {
-    const int entry0 = (2 * wave) * 32 + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
+    const int entry0 = (PP * wave) * 32 + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
     dvoff1 = (entry0 >> 8) * 4096 + (entry0 & 255) * 16 + half * 8;
     dvoff2 = (entry0 >> 6) * 4096 + (entry0 & 63) * 16 + half * 8;
   }
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c_planes), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(o_planes), 0, 0x7fffffff, 0x00020000);
   const int plane_bytes = (int)plane_stride * 2;
+  // piece i of this wave (i < PP): LDS slot block PP*wave + i; its source lies i * 512 elements further in a GEMM 1
+  // stage ([slab][256 rows][16]) and (i >> 1) * 4096 + (i & 1) * 512 in a GEMM 2 stage ([k slab][64 rows][16]) when a
+  // wave covers more than one k slab (PP = 4), i * 512 otherwise
 #define FUSED_DMA_STAGE(t)                                                                                   \
   {                                                                                                          \
     const int u_ = (t) - NS1;                                                                                \
     const int sbase = (t) < NS1 ? SPS * (t) * 4096 * 2 : ((KPS * (u_ % SPQ)) * 4096 + 64 * (u_ / SPQ) * 16) * 2; \
-    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                                       \
-      unsigned short* d0 = wbuf + ((t) & 1) * BUF + pl * PLANE + (2 * wave) * 512;                           \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds((t) < NS1 ? rs_c : rs_o, (__attribute__((address_space(3))) void*)d0, 16, \
-                                               ((t) < NS1 ? dvoff1 : dvoff2) * 2, sbase + pl * plane_bytes, 0, 0);      \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds((t) < NS1 ? rs_c : rs_o,                                      \
-                                               (__attribute__((address_space(3))) void*)d0, 16,              \
-                                               ((t) < NS1 ? dvoff1 : dvoff2) * 2, sbase + pl * plane_bytes, 1024, 0);   \
-    }                                                                                                        \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                         \
+      _Pragma("unroll") for (int i = 0; i < PP; ++i) {                                                       \
+        const int src_off = ((t) < NS1 || PP == 2) ? i * 512 : (i >> 1) * 4096 + (i & 1) * 512;             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                            \
+            (t) < NS1 ? rs_c : rs_o,                                                                         \
+            (__attribute__((address_space(3))) void*)(wbuf + ((t) & 1) * BUF + pl * PLANE + (PP * wave + i) * 512), 16, \
+            ((t) < NS1 ? dvoff1 : dvoff2) * 2, sbase + pl * plane_bytes + src_off * 2, 0, 0);                \
+      }                                                                                                      \
   }
 #define FUSED_PIPE_BEGIN(t)                                         \
-  if constexpr (kDma) {                                             \
+  if constexpr (kNoSync) {                                          \
+  } else if constexpr (kDma) {                                      \
+    if (G_::ALIAS && (t) == NS1) __syncthreads();   /* every wave has left the scratch = stage buffer 1 */ \
     if ((t) + 1 < NSTAGE) {                                         \
       FUSED_DMA_STAGE((t) + 1)                                      \
       __builtin_amdgcn_sched_barrier(0);                            \
@@ -256,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
   // end of iteration t: the requests of stage t+1 must have landed before the barrier.  In GEMM 1 with the e
   // stream on the DMA queue as well, the two youngest requests are slab t+2 of e, which may stay in flight.
 #define FUSED_PIPE_END(t)                                                        \
-  if ((t) + 1 < NSTAGE) {                                                        \
+  if (!kNoSync && (t) + 1 < NSTAGE) {                                            \
     if constexpr (kDma) {                                                        \
       if (kDmaE && !L0 && (t) + 2 < 16) __builtin_amdgcn_s_waitcnt(0x0F72); /* vmcnt(2) */ \
       else __builtin_amdgcn_s_waitcnt(0x0F70);                       /* vmcnt(0) */ \
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(64 * NW, 2) void edge_layer_fused_kernel(
       } else {
         c0 = er[ks % RING][0];
         c1 = er[ks % RING][1];
-        if (ks + RING < 16) {
+        if (!kNoE && ks + RING < 16) {
           er[ks % RING][0] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512 + loff);
           er[ks % RING][1] = *reinterpret_cast<const v4f*>(etile + ((ks + RING) * 512 + 256) + loff);
         }
@@ -697,8 +718,9 @@ static hipError_t launch_fused_t(float* e, const float* node4, const int* row, c
     if (er != hipSuccess) return er;
     attr_set = true;
   }
-  const unsigned grid = (unsigned)((n_edges + 32 * NW - 1) / (32 * NW));
-  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP>), dim3(grid), dim3(64 * NW), fused::Geo<NW>::LDS_TOTAL, stream,
+  constexpr int WV = fused::geo_waves(NW);
+  const unsigned grid = (unsigned)((n_edges + 32 * WV - 1) / (32 * WV));
+  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP>), dim3(grid), dim3(64 * WV), fused::Geo<NW>::LDS_TOTAL, stream,
                      e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
                      time_on_edge, part, direct, g_fused_dbg, l0_table, l0_x, l0_perm, gn_tile);
   return hipGetLastError();
@@ -730,6 +752,11 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     case 1024: return launch_fused_t<FFp16, 1024, FUSED_NW>(FUSED_ARGS);
     case 2048: return launch_fused_t<FFp16, 2048, FUSED_NW>(FUSED_ARGS);
     case 4096: return launch_fused_t<FFp16, 4096, FUSED_NW>(FUSED_ARGS);
+    case 140: return launch_fused_t<FFp16, 0, 40>(FUSED_ARGS);                 // geometry 40: 4 waves, 32 KiB stages
+    case 155: return launch_fused_t<FFp16, 15, 40>(FUSED_ARGS);
+    case 16399: return launch_fused_t<FFp16, 16399, FUSED_NW>(FUSED_ARGS);   // 15 + no stage refills / barriers
+    case 32783: return launch_fused_t<FFp16, 32783, FUSED_NW>(FUSED_ARGS);   // 15 + no e stream
+    case 49167: return launch_fused_t<FFp16, 49167, FUSED_NW>(FUSED_ARGS);   // 15 + both
     case 100: return launch_fused_t<FFp16, 0, 12 - FUSED_NW>(FUSED_ARGS);   // the other workgroup geometry (A/B)
     case 116: return launch_fused_t<FFp16, 16, 12 - FUSED_NW>(FUSED_ARGS);
     default: return hipErrorInvalidValue;
