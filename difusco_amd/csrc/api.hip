@@ -112,7 +112,7 @@ Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk)
   w.table_in = (float*)take(sizeof(float) * 2 * H);
   w.table = (float*)take(sizeof(float) * 2 * H);
   w.stats = (float*)take(sizeof(float) * S * 64);
-  w.partial = (double*)take(sizeof(double) * (size_t)S * (nblk < 64 ? 64 : nblk) * 64);
+  w.partial = (double*)take(sizeof(double) * (size_t)S * (nblk < 256 ? 256 : nblk) * 64);
   w.part = (float*)take(H == 256 ? sizeof(float) * fused_part_floats(E) : 0);
   w.direct = (float*)take(H == 256 ? sizeof(float) * N * H : 0);
   w.gn_tile = (float*)take(H == 256 ? sizeof(float) * ((E + 255) / 256 * 8) * 64 : 0);   // per 32-edge tile: 32 x (sum, sumsq)

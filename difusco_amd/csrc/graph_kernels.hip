@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void gn_partial_tiled_kernel(const float* __re
 }
 
 // GroupNorm partial sums that the last fused edge layer left per tile (gn_tile[tile][32 groups][sum, sumsq] floats)
-// -> partial[64 blocks][64] doubles in the all-groups-per-block layout of gn_finalize_kernel (group stride 1).
+// -> partial[256 blocks][64] doubles in the all-groups-per-block layout of gn_finalize_kernel (group stride 1).
 __global__ __launch_bounds__(256) void gn_tiles_reduce_kernel(const float* __restrict__ gn_tile, long long n_tiles,
                                                               double* __restrict__ partial) {
   __shared__ double red[4][64];
@@ -670,14 +670,14 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
                              unsigned long long seed, unsigned long long offset, float* xt_out, float* pred_out,
                              float* prob_out, hipStream_t stream, const float* gn_tile) {
   if (rows == 0) return hipSuccess;
-  if (nblk < 8 || nblk % 8 != 0) return hipErrorInvalidValue;   // (with gn_tile, partial must hold 64 * 64 doubles)
+  if (nblk < 8 || nblk % 8 != 0) return hipErrorInvalidValue;   // (with gn_tile, partial must hold 256 * 64 doubles)
   PostParams pp;
   for (int i = 0; i < 8; ++i) pp.p[i] = post[i];
   pp.rand_mode = rand_mode; pp.rand = rand; pp.seed = seed; pp.offset = offset;
   const long long n_tiles = (rows + 31) / 32;
   if (gn_tile) {   // statistics come from the last fused layer: no pass over feat
-    hipLaunchKernelGGL(gn_tiles_reduce_kernel, dim3(64), dim3(256), 0, stream, gn_tile, n_tiles, partial);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, 64, 8, 1, stats);
+    hipLaunchKernelGGL(gn_tiles_reduce_kernel, dim3(256), dim3(256), 0, stream, gn_tile, n_tiles, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, 256, 8, 1, stats);
   } else {
     hipLaunchKernelGGL(gn_partial_tiled_kernel, dim3(nblk), dim3(256), 0, stream, feat, n_tiles, partial);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, nblk, 8, 8, stats);
