@@ -491,6 +491,7 @@ int difusco_debug_set(int key, int value) {
   if (key == 2) { difusco::g_fused_variant = value; return DIFUSCO_OK; }
   if (key == 3) { difusco::g_fused_l0_fold = value; return DIFUSCO_OK; }
   if (key == 4) { difusco::g_fused_gn_fold = value; return DIFUSCO_OK; }
+  if (key == 6) { difusco::g_fused_lds_pad = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }
 

@@ -700,6 +700,7 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
 
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 int g_fused_ablate = 0;   // profiling knob (difusco_debug_set), 0 in production
+int g_fused_lds_pad = 0;  // profiling only (difusco_debug_set key 6)
 int g_fused_gn_fold = 1;  // 1: the last layer emits the head's GroupNorm partial sums (difusco_debug_set key 4)
 int g_fused_l0_fold = 1;  // 1: the first layer reads its edge input from the 2-row table (difusco_debug_set key 3)
 unsigned long long* g_fused_dbg = nullptr;   // profiling: device buffer for phase timestamps, [n_tiles][8]
@@ -714,13 +715,15 @@ static hipError_t launch_fused_t(float* e, const float* node4, const int* row, c
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0, GNP>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, fused::Geo<NW>::LDS_TOTAL);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er != hipSuccess) return er;
     attr_set = true;
   }
   constexpr int WV = fused::geo_waves(NW);
   const unsigned grid = (unsigned)((n_edges + 32 * WV - 1) / (32 * WV));
-  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP>), dim3(grid), dim3(64 * WV), fused::Geo<NW>::LDS_TOTAL, stream,
+  // profiling: g_fused_lds_pad extra bytes of dynamic LDS lower the number of co-resident workgroups per CU
+  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP>), dim3(grid), dim3(64 * WV),
+                     fused::Geo<NW>::LDS_TOTAL + g_fused_lds_pad, stream,
                      e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
                      time_on_edge, part, direct, g_fused_dbg, l0_table, l0_x, l0_perm, gn_tile);
   return hipGetLastError();

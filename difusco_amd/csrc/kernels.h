@@ -43,6 +43,7 @@ hipError_t launch_edge_layer_fused_gn(int mode, float* e, const float* node4, co
                                       const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                       int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream);
 extern int g_fused_gn_fold;
+extern int g_fused_lds_pad;
 // software-pipelined persistent variant of the same layer (edge_layer_pipe.hip); same arguments and results
 hipError_t launch_edge_layer_pipe(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
                                   const unsigned short* c_planes, const unsigned short* o_planes,

@@ -40,6 +40,7 @@ def run(e, h):
 
 # interleaved rounds (variants alternate inside one process; report median and min - cdna guide rule 24)
 ROUNDS, ITERS = 7, 5
+L.difusco_debug_set(6, int(os.environ.get('LDS_PAD', '0')))      # profiling: extra LDS bytes -> fewer workgroups per CU
 times = {m: [] for m in masks}
 e, h = e0.clone(), h0.clone()
 for r in range(ROUNDS + 1):
