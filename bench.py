@@ -119,6 +119,9 @@ def main():
                     "pass instead of reading it from the 2-row table inside the fused kernel")
     ap.add_argument("--no-gn-fold", action="store_true", help="A/B: head GroupNorm statistics by a separate pass over e "
                     "instead of per-tile partial sums emitted by the last fused layer")
+    ap.add_argument("--gn-stats", default="per_shard_call", choices=["per_shard_call", "global"],
+                    help="head GroupNorm statistics: over each rank's own call (default, no collective in the loop) or "
+                         "over the whole sharded batch (one all-reduce of 65 doubles per step)")
     ap.add_argument("--precision", default="fp16x3", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
                     help="arithmetic of the E-row linears: exact fp32 MFMA, or fp32 split into 2/3 bf16 planes "
                          "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
@@ -157,7 +160,7 @@ def main():
         _lib.check(_lib.lib().difusco_debug_set(3, 0))
     if args.no_gn_fold:
         _lib.check(_lib.lib().difusco_debug_set(4, 0))
-    from difusco_amd.dist import GN_STATS_MODE, engine_from_broadcast, shard_range
+    from difusco_amd.dist import engine_from_broadcast, gn_allreduce, shard_range
     from difusco_amd.engine import DenoiseEngine
     from difusco_amd.models import MISModel, TSPModel
     from difusco_amd.schedules import InferenceSchedule
@@ -172,7 +175,8 @@ def main():
     margs = dict(diffusion_type=wl["diffusion"], diffusion_schedule="linear", diffusion_steps=1000,
                  inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn if not mis else -1,
                  n_layers=LAYERS, hidden_dim=H, inference_trick="ddim")
-    model = (MISModel if mis else TSPModel)(margs, engine=engine, seed=1234 + rank)
+    gn_reduce = gn_allreduce() if (args.gn_stats == "global" and world > 1) else None
+    model = (MISModel if mis else TSPModel)(margs, engine=engine, seed=1234 + rank, gn_reduce=gn_reduce)
 
     # this rank's shard of the global batch (weak scaling: graphs_per_gpu fixed)
     G_total = args.graphs_per_gpu * world
@@ -251,7 +255,7 @@ def main():
                                    f"(global batch {G_total}), H={H}, {LAYERS} layers",
                        "name": args.workload, "graphs_per_gpu": args.graphs_per_gpu, "global_batch": G_total,
                        "nodes": args.nodes, "knn": args.knn, "nodes_rank0": N_local, "edges_rank0": E_local,
-                       "gn_stats": GN_STATS_MODE,
+                       "gn_stats": args.gn_stats,
                        "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision,
                        "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3")},
         }

@@ -5,7 +5,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
@@ -44,6 +44,7 @@ class StepArgs(ctypes.Structure):
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("stream", ctypes.c_void_p),
         ("precision", ctypes.c_int32), ("no_fusion", ctypes.c_int32),
         ("row", ctypes.c_void_p),
+        ("gn_phase", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("gn_sums", ctypes.c_void_p),
     ]
 
 

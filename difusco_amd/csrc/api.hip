@@ -228,6 +228,10 @@ int difusco_denoise_step(const difusco_step_args* a) {
     return fail(DIFUSCO_EINVAL, "n_segments >= 1, seg_ptr required when > 1");
   if (a->rand_mode == DIFUSCO_RAND_INJECTED && !a->rand) return fail(DIFUSCO_EINVAL, "injected randomness needs rand");
   if (a->rand_mode < 0 || a->rand_mode > 2) return fail(DIFUSCO_EINVAL, "unknown rand_mode %d", a->rand_mode);
+  if (a->gn_phase < 0 || a->gn_phase > 2) return fail(DIFUSCO_EINVAL, "gn_phase must be 0, 1 or 2");
+  if (a->gn_phase != 0 && (a->n_segments != 1 || !a->gn_sums))
+    return fail(DIFUSCO_EINVAL, "gn_phase %d needs n_segments == 1 and a gn_sums buffer of 65 doubles", a->gn_phase);
+  const bool head_only = a->gn_phase == 2;   // everything up to the statistics was done by the phase-1 call
   const bool needs_draw = a->post[4] != 0.0f;
   if (needs_draw && a->rand_mode == DIFUSCO_RAND_NONE)
     return fail(DIFUSCO_EINVAL, "this step draws random numbers: rand_mode must not be NONE");
@@ -277,6 +281,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                        difusco::g_fused_ablate == 0 && (tsp ? a->xt_is_binary != 0 : true);
 
   // per-layer time bias rows: time_layer_l(time_embed(timestep_embedding(t)))   [L,H]
+  if (!head_only)
   PROF(PROF_EMBED, launch_time_bias(a->t, H, L, G(DIFUSCO_W_TIME_FREQS), G(DIFUSCO_W_TIME0_W), G(DIFUSCO_W_TIME0_B),
                                     G(DIFUSCO_W_TIME2_W), G(DIFUSCO_W_TIME2_B), LW(0, 0), lo.layer_stride,
                                     lo.off[DIFUSCO_W_GLOBAL_COUNT + DIFUSCO_WL_TIME_W] - lo.off[DIFUSCO_W_GLOBAL_COUNT],
@@ -285,7 +290,9 @@ int difusco_denoise_step(const difusco_step_args* a) {
 
   // input embeddings (gnn_encoder.py:394-395 TSP, :405-407 MIS).  node4 doubles as scratch for the
   // sinusoidal node features before the first layer overwrites it.
-  if (tsp) {
+  if (head_only) {
+    // (phase 2: e / h of the phase-1 call are still in the workspace)
+  } else if (tsp) {
     PROF(PROF_EMBED, launch_pos_embed(a->points, G(DIFUSCO_W_DIMT_POS), (int)N, H, ws.node4, st))
     PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
                                        H, H, H, st))
@@ -324,7 +331,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
 
   // the GNN layers (gnn_encoder.py:425-449)
   const long long split_off = a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0;  // fp16 planes follow bf16
-  for (int l = 0; l < L; ++l) {
+  for (int l = 0; l < (head_only ? 0 : L); ++l) {
     if (a->precision != DIFUSCO_PREC_FP32 && H == 256) {   // node rows on the same split-precision matrix-core path
       const unsigned short* npl = reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_NODE4_PLANES)) +
                                   (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * 4 * H * H : 0);
@@ -385,13 +392,14 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                       ws.partial, ws.stats, G(DIFUSCO_W_OUT_GN_W), G(DIFUSCO_W_OUT_GN_B),
                                       G(DIFUSCO_W_OUT_CONV_W), G(DIFUSCO_W_OUT_CONV_B), a->perm, a->xt, a->post,
                                       a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st,
-                                      gn_fold ? ws.gn_tile : nullptr))
+                                      gn_fold ? ws.gn_tile : nullptr, a->gn_phase, a->gn_sums))
     return DIFUSCO_OK;
   }
   PROF(PROF_HEAD, launch_head(H, C, tsp ? ws.e : ws.h, a->n_segments > 1 ? a->seg_ptr : nullptr, a->n_segments, out_rows,
                               gn_blocks_for(out_rows), ws.partial, ws.stats, G(DIFUSCO_W_OUT_GN_W), G(DIFUSCO_W_OUT_GN_B),
                               G(DIFUSCO_W_OUT_CONV_W), G(DIFUSCO_W_OUT_CONV_B), tsp ? a->perm : nullptr, a->xt, a->post,
-                              a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st))
+                              a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st,
+                              a->gn_phase, a->gn_sums))
 #undef PROF
   return DIFUSCO_OK;
 }

@@ -283,7 +283,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 // holds groups 4 (b % 8) .. 4 (b % 8) + 3 (tiled kernel).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, const int* __restrict__ seg_ptr,
                                                           long long total_rows, int nblk, int ch_per_group,
-                                                          int group_stride_blocks, float* __restrict__ stats) {
+                                                          int group_stride_blocks, float* __restrict__ stats,
+                                                          double* __restrict__ sums_out) {
+  // sums_out (one segment only): instead of the statistics, write the 32 x (sum, sum of squares) and the row count
+  // [64] - the quantities a caller adds over the shards of a batch (difusco_step_args.gn_phase 1)
   __shared__ double red[4][64];
   const int seg = blockIdx.x;
   const int c = threadIdx.x >> 6, gw = threadIdx.x & 63, g = gw >> 1;
@@ -300,6 +303,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     const double s = ((red[0][2 * gg] + red[1][2 * gg]) + red[2][2 * gg]) + red[3][2 * gg];
     const double q = ((red[0][2 * gg + 1] + red[1][2 * gg + 1]) + red[2][2 * gg + 1]) + red[3][2 * gg + 1];
     const long long rows = seg_ptr ? (long long)(seg_ptr[seg + 1] - seg_ptr[seg]) : total_rows;
+    if (sums_out) {
+      sums_out[2 * gg] = s;
+      sums_out[2 * gg + 1] = q;
+      if (gg == 0) sums_out[64] = (double)rows;
+      return;
+    }
     const double cnt = (double)rows * ch_per_group;
     const double mean = s / cnt;
     double var = q / cnt - mean * mean;
@@ -307,6 +316,18 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     stats[(seg * 32 + gg) * 2 + 0] = (float)mean;
     stats[(seg * 32 + gg) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
   }
+}
+
+// statistics from (possibly shard-summed) group sums: sums[2g] = sum, sums[2g+1] = sum of squares, sums[64] = rows
+__global__ void gn_stats_from_sums_kernel(const double* __restrict__ sums, int ch_per_group, float* __restrict__ stats) {
+  const int gg = threadIdx.x;
+  if (gg >= 32) return;
+  const double cnt = sums[64] * ch_per_group;
+  const double mean = sums[2 * gg] / cnt;
+  double var = sums[2 * gg + 1] / cnt - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  stats[gg * 2 + 0] = (float)mean;
+  stats[gg * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
 }
 
 // ---- posterior arithmetic (shared by the fused head and the stand-alone kernels) -------------------
@@ -603,8 +624,10 @@ hipError_t launch_head(int H, int C, const float* feat, const int* seg_ptr, int 
                        int nblk, double* partial, float* stats, const float* gn_w, const float* gn_b,
                        const float* conv_w, const float* conv_b, const int* perm, const float* xt, const float* post,
                        int rand_mode, const float* rand, unsigned long long seed, unsigned long long offset,
-                       float* xt_out, float* pred_out, float* prob_out, hipStream_t stream) {
+                       float* xt_out, float* pred_out, float* prob_out, hipStream_t stream, int gn_phase,
+                       double* gn_sums) {
   if (total_rows == 0) return hipSuccess;
+  if (gn_phase != 0 && (n_segments != 1 || !gn_sums)) return hipErrorInvalidValue;
   PostParams pp;
   for (int i = 0; i < 8; ++i) pp.p[i] = post[i];
   pp.rand_mode = rand_mode;
@@ -612,10 +635,15 @@ hipError_t launch_head(int H, int C, const float* feat, const int* seg_ptr, int 
   pp.seed = seed;
   pp.offset = offset;
   dim3 grid((unsigned)nblk, (unsigned)n_segments);
-  DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((gn_partial_kernel<VEC>), grid, dim3(256), 0, stream, feat, seg_ptr,
-                                             total_rows, partial))
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segments), dim3(256), 0, stream, partial, seg_ptr, total_rows, nblk, H / 32,
-                     1, stats);
+  if (gn_phase != 2) {
+    DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((gn_partial_kernel<VEC>), grid, dim3(256), 0, stream, feat, seg_ptr,
+                                               total_rows, partial))
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segments), dim3(256), 0, stream, partial, seg_ptr, total_rows, nblk, H / 32,
+                       1, stats, gn_phase == 1 ? gn_sums : (double*)nullptr);
+    if (gn_phase == 1) return hipGetLastError();
+  } else {
+    hipLaunchKernelGGL(gn_stats_from_sums_kernel, dim3(1), dim3(64), 0, stream, gn_sums, H / 32, stats);
+  }
   if (C == 2) {
     DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((head_apply_kernel<VEC, 2>), grid, dim3(256), 0, stream, feat, seg_ptr,
                                                total_rows, stats, gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out,
@@ -668,20 +696,27 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
                              const float* gn_w, const float* gn_b, const float* conv_w, const float* conv_b,
                              const int* perm, const float* xt, const float* post, int rand_mode, const float* rand,
                              unsigned long long seed, unsigned long long offset, float* xt_out, float* pred_out,
-                             float* prob_out, hipStream_t stream, const float* gn_tile) {
+                             float* prob_out, hipStream_t stream, const float* gn_tile, int gn_phase, double* gn_sums) {
   if (rows == 0) return hipSuccess;
+  if (gn_phase != 0 && !gn_sums) return hipErrorInvalidValue;
   if (nblk < 8 || nblk % 8 != 0) return hipErrorInvalidValue;   // (with gn_tile, partial must hold 256 * 64 doubles)
   PostParams pp;
   for (int i = 0; i < 8; ++i) pp.p[i] = post[i];
   pp.rand_mode = rand_mode; pp.rand = rand; pp.seed = seed; pp.offset = offset;
   const long long n_tiles = (rows + 31) / 32;
-  if (gn_tile) {   // statistics come from the last fused layer: no pass over feat
+  double* sums_out = gn_phase == 1 ? gn_sums : (double*)nullptr;
+  if (gn_phase == 2) {
+    hipLaunchKernelGGL(gn_stats_from_sums_kernel, dim3(1), dim3(64), 0, stream, gn_sums, 8, stats);
+  } else if (gn_tile) {   // statistics come from the last fused layer: no pass over feat
     hipLaunchKernelGGL(gn_tiles_reduce_kernel, dim3(256), dim3(256), 0, stream, gn_tile, n_tiles, partial);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, 256, 8, 1, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, 256, 8, 1, stats,
+                       sums_out);
   } else {
     hipLaunchKernelGGL(gn_partial_tiled_kernel, dim3(nblk), dim3(256), 0, stream, feat, n_tiles, partial);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, nblk, 8, 8, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, nblk, 8, 8, stats,
+                       sums_out);
   }
+  if (gn_phase == 1) return hipGetLastError();
   long long blocks = (n_tiles + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   if (C == 2) {

@@ -70,7 +70,8 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
                              const float* gn_w, const float* gn_b, const float* conv_w, const float* conv_b,
                              const int* perm, const float* xt, const float* post, int rand_mode, const float* rand,
                              unsigned long long seed, unsigned long long offset, float* xt_out, float* pred_out,
-                             float* prob_out, hipStream_t stream, const float* gn_tile = nullptr);
+                             float* prob_out, hipStream_t stream, const float* gn_tile = nullptr, int gn_phase = 0,
+                             double* gn_sums = nullptr);
 hipError_t launch_edge_gate_aggregate(int H, int n_nodes, const int* rowptr, const int* col, const float* node4,
                                       float* ce_act, float* h, const float* nh_w, const float* nh_b, const float* ne_w,
                                       const float* ne_b, const float* ol_w, const float* ol_b, const float* tbias,
@@ -80,7 +81,8 @@ hipError_t launch_head(int H, int C, const float* feat, const int* seg_ptr, int 
                        int nblk, double* partial, float* stats, const float* gn_w, const float* gn_b,
                        const float* conv_w, const float* conv_b, const int* perm, const float* xt, const float* post,
                        int rand_mode, const float* rand, unsigned long long seed, unsigned long long offset,
-                       float* xt_out, float* pred_out, float* prob_out, hipStream_t stream);
+                       float* xt_out, float* pred_out, float* prob_out, hipStream_t stream, int gn_phase = 0,
+                       double* gn_sums = nullptr);
 hipError_t launch_categorical_posterior(const float* logits, const float* xt, const float* post, int rand_mode,
                                         const float* rand, unsigned long long seed, unsigned long long offset,
                                         float* xt_out, float* prob_out, long long n, hipStream_t stream);

@@ -16,7 +16,17 @@ import torch.distributed as dist
 from .weights import infer_config, pack_state_dict
 from . import _lib
 
-GN_STATS_MODE = "per_shard_call"
+GN_STATS_MODE = "per_shard_call"      # the default; "global" = pass gn_allreduce(group) as the models' gn_reduce
+
+
+def gn_allreduce(group=None):
+    """``gn_reduce`` callable for :class:`~difusco_amd.engine.DenoiseEngine.step`: one all-reduce (SUM) of 65 doubles
+    per denoise step makes every rank normalise the head with the statistics of the WHOLE sharded batch (SURVEY 8(e)
+    option "global statistics" = the reference called once over all graphs).  This is the only collective the loop
+    can contain, and only when asked for; the default per-shard statistics need none."""
+    def reduce_(sums: torch.Tensor):
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return reduce_
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

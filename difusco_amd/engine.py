@@ -49,9 +49,15 @@ class DenoiseEngine:
     def step(self, g: CsrGraph, task: int, diffusion: int, xt: torch.Tensor, t: float, post: np.ndarray,
              points: Optional[torch.Tensor] = None, xt_is_binary: bool = False,
              rand: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
-             want_pred: bool = False, want_prob: bool = False):
+             want_pred: bool = False, want_prob: bool = False, gn_reduce=None):
         """xt: fp32, TSP [E] in caller edge order / MIS [N].  Returns (xt_next, pred|None, prob|None);
-        asynchronous on the current stream."""
+        asynchronous on the current stream.
+
+        ``gn_reduce``: optional callable taking the device tensor of 65 doubles (32 x (sum, sum of squares) of the head
+        GroupNorm input over THIS call's rows + the row count) and adding the other shards' values in place - e.g.
+        ``lambda t: torch.distributed.all_reduce(t)``.  The step then runs in two phases around it, which makes a
+        batch sharded over several GPUs use the statistics of the whole batch, like the reference's single call over
+        all graphs (SURVEY 8(e) "global statistics").  Without it the statistics are those of this call."""
         dev = self.device
         xt = xt.to(dev, dtype=torch.float32).contiguous().reshape(-1)
         rows = g.n_edges if task == _lib.TASK_TSP else g.n_nodes
@@ -95,7 +101,19 @@ class DenoiseEngine:
         a.precision = _lib.PRECISIONS[self.precision]
         a.no_fusion = 0 if self.fused else 1
         a.row = _ptr(g.row)
+        a.gn_phase, a.gn_sums = 0, None
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
+            if gn_reduce is None:
+                _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
+            else:
+                if g.n_segments != 1:
+                    raise ValueError("global GroupNorm statistics need one statistic segment per call")
+                sums = torch.zeros(65, dtype=torch.float64, device=dev)
+                a.gn_sums = _ptr(sums)
+                a.gn_phase = 1
+                _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
+                gn_reduce(sums)
+                a.gn_phase = 2
+                _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
         self.calls += 1
         return xt_out, pred, prob

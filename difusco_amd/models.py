@@ -44,7 +44,7 @@ class COMetaModel:
 
     def __init__(self, param_args=None, state_dict=None, node_feature_only=False, device="cuda:0",
                  seed: Optional[int] = None, engine: Optional[DenoiseEngine] = None, precision: str = "fp16x3",
-                 fused: bool = True):
+                 fused: bool = True, gn_reduce=None):
         args = dict(_DEFAULTS)
         if param_args is not None:
             args.update(vars(param_args) if not isinstance(param_args, dict) else param_args)
@@ -75,6 +75,9 @@ class COMetaModel:
         self.device = engine.device
         self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
         self._graph_cache = {}
+        # optional: shard-summing callable for the head GroupNorm statistics (difusco_amd.dist.gn_allreduce); None =
+        # statistics of each call's own rows, the reference's behaviour for that call
+        self.gn_reduce = gn_reduce
 
     # ---- graph handling --------------------------------------------------------------------------
     def prepare_graph(self, edge_index: torch.Tensor, num_nodes: int) -> CsrGraph:
@@ -118,7 +121,7 @@ class COMetaModel:
         out, pred, prob = self.model.step(
             g, task, _lib.CATEGORICAL, xt, float(t), post, points=points, xt_is_binary=True,
             rand=uniform if target_t > 0 else None, seed=self.seed, offset=self._next_offset(),
-            want_pred=return_aux, want_prob=return_aux)
+            want_pred=return_aux, want_prob=return_aux, gn_reduce=self.gn_reduce)
         return (out, pred, prob) if return_aux else out
 
     def _gaussian(self, g, task, points, xt, t, target_t, noise, return_aux):
@@ -129,7 +132,8 @@ class COMetaModel:
         post[:5] = self.diffusion.posterior_constants(t, target_t, self.args.inference_trick)
         out, pred, _ = self.model.step(
             g, task, _lib.GAUSSIAN, xt, float(t), post, points=points, xt_is_binary=False,
-            rand=noise if post[4] != 0 else None, seed=self.seed, offset=self._next_offset(), want_pred=return_aux)
+            rand=noise if post[4] != 0 else None, seed=self.seed, offset=self._next_offset(), want_pred=return_aux,
+            gn_reduce=self.gn_reduce)
         return (out, pred) if return_aux else out
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 5
+#define DIFUSCO_ABI_VERSION 6
 
 enum {
   DIFUSCO_OK = 0,
@@ -157,6 +157,15 @@ typedef struct difusco_step_args {
                              BF16X3 / FP16X3); 1: always run the unfused kernel sequence (A/B and parity tests) */
   const int32_t* row;     /* [n_edges] centre node of each CSR slot (device); required for the fused kernel,
                              may be NULL otherwise */
+  /* Head GroupNorm statistics across several calls (one per GPU of a sharded batch), SURVEY 8(e) option "global
+   * statistics" = the reference's single call over all graphs.  gn_phase 0: the whole step in one call (statistics
+   * of THIS call's rows).  1: run up to the statistics, write the 32 x (sum, sum of squares) of this call's rows
+   * and the row count to gn_sums[0..63], gn_sums[64] (device doubles) and return; the caller adds gn_sums over the
+   * shards (e.g. one all-reduce of 65 doubles).  2: finish the step of the preceding phase-1 call (same arguments,
+   * same workspace) with the statistics in gn_sums.  Needs n_segments == 1. */
+  int32_t gn_phase;
+  int32_t reserved0;
+  double* gn_sums;
 } difusco_step_args;
 
 size_t difusco_workspace_bytes(int hidden, int n_layers, int n_nodes, int n_edges, int n_segments);

@@ -669,3 +669,57 @@ def test_free_running_trajectory(dev, task):
         agreed += 1
     print(f"{task}: {agreed} free-running steps bit-identical")
     assert agreed >= 8
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_global_groupnorm_statistics_over_shards(dev, fused):
+    """SURVEY 8(e) "global statistics": a batch sharded over two "ranks" (two models in this process, the all-reduce
+    emulated by adding the two 65-double buffers) must reproduce the single call over all graphs - the reference's
+    behaviour for the whole batch - while the default per-shard statistics differ from it (F3).  Also: the two-phase
+    step with an identity reduction is bitwise the one-shot step."""
+    from difusco_amd import TSPModel
+    H, Lyr, N, K, G = 256, 3, 96, 12, 4
+    p = O.init_params(H, Lyr, 2, seed=31)
+    insts = [O.tsp_instance(N, K, seed=70 + g) for g in range(G)]
+    pts = torch.from_numpy(np.concatenate([i[0] for i in insts])).to(dev)
+    ei = torch.from_numpy(np.concatenate([i[1] + g * N for g, i in enumerate(insts)], axis=1)).to(dev)
+    E1 = K * N
+    gen = torch.Generator().manual_seed(5)
+    xt = (torch.randn(G * E1, generator=gen) > 0).float().to(dev)
+    u = torch.rand(G * E1, generator=gen)
+    t, tt = np.array([300]), np.array([280])
+    kw = dict(device=dev, fused=fused)
+    whole = TSPModel(_args("categorical", K, H=H, L=Lyr), p, **kw)
+    ref_out, ref_logits, _ = whole.categorical_denoise_step(pts, xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    # identity reduction == one-shot
+    ident = TSPModel(_args("categorical", K, H=H, L=Lyr), p, gn_reduce=lambda s: None, **kw)
+    o2, l2, _ = ident.categorical_denoise_step(pts, xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    assert torch.equal(l2, ref_logits) and torch.equal(o2, ref_out)
+
+    # two shards of two graphs each; the "all-reduce" adds the partner's sums (computed by a phase-1-only pre-pass)
+    half = G // 2
+    shards = []
+    for r in range(2):
+        sl_n, sl_e = slice(r * half * N, (r + 1) * half * N), slice(r * half * E1, (r + 1) * half * E1)
+        shards.append((pts[sl_n], ei[:, sl_e] - r * half * N, xt[sl_e], u[sl_e]))
+    sums = []
+    for r in range(2):
+        grab = {}
+        m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, gn_reduce=lambda s, grab=grab: grab.setdefault("s", s.clone()), **kw)
+        m.categorical_denoise_step(shards[r][0], shards[r][2], t, dev, shards[r][1], target_t=tt, uniform=shards[r][3])
+        sums.append(grab["s"])
+    assert sums[0][64].item() == half * E1
+    outs_global, outs_local = [], []
+    for r in range(2):
+        other = sums[1 - r]
+        m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, gn_reduce=lambda s, other=other: s.add_(other), **kw)
+        outs_global.append(m.categorical_denoise_step(shards[r][0], shards[r][2], t, dev, shards[r][1], target_t=tt,
+                                                      uniform=shards[r][3], return_aux=True)[1])
+        m0 = TSPModel(_args("categorical", K, H=H, L=Lyr), p, **kw)
+        outs_local.append(m0.categorical_denoise_step(shards[r][0], shards[r][2], t, dev, shards[r][1], target_t=tt,
+                                                      uniform=shards[r][3], return_aux=True)[1])
+    glob, loc = torch.cat(outs_global), torch.cat(outs_local)
+    e_glob, e_loc = (glob - ref_logits).abs().max().item(), (loc - ref_logits).abs().max().item()
+    print(f"sharded vs whole-batch logits: global statistics {e_glob:.2e}, per-shard statistics {e_loc:.2e}")
+    assert e_glob < 2e-5
+    assert e_loc > 10 * e_glob          # per-shard statistics are a different (documented) composition
