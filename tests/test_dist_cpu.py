@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from difusco_amd import synthetic
-from difusco_amd.dist import broadcast_weights, shard_range
+from difusco_amd.dist import broadcast_weights, gn_allreduce, shard_range
 from oracle import difusco_oracle as O
 
 
@@ -58,7 +58,11 @@ def _worker(rank, world, port, ret):
         lo, hi = shard_range(5, rank, world)
         # every rank builds ITS graphs only; no collective is needed afterwards
         pts, ei = synthetic.tsp_batch(20, 4, range(lo, hi))
-        ret[rank] = (cfg, float(blob.double().sum()), blob.numel(), (lo, hi), tuple(pts.shape), tuple(ei.shape))
+        # the optional global-statistics exchange: 32 x (sum, sumsq) + row count, summed over the ranks in place
+        sums = torch.arange(65, dtype=torch.float64) * (rank + 1)
+        gn_allreduce()(sums)
+        ret[rank] = (cfg, float(blob.double().sum()), blob.numel(), (lo, hi), tuple(pts.shape), tuple(ei.shape),
+                     bool(torch.equal(sums, torch.arange(65, dtype=torch.float64) * 3)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -77,3 +81,4 @@ def test_broadcast_and_shard_two_processes():
     assert ret[0][1] == ret[1][1] == float(ref.double().sum())
     assert ret[0][3] == (0, 3) and ret[1][3] == (3, 5)
     assert ret[0][4] == (60, 2) and ret[1][4] == (40, 2)
+    assert ret[0][6] and ret[1][6]            # gn_allreduce summed the 65 doubles over both ranks
