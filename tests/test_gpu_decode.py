@@ -237,3 +237,22 @@ def test_mis_decode_batch_and_properties(dev):
     assert np.all(covered | (sol == 1))                                   # maximal
     adj = scipy.sparse.coo_matrix((np.ones_like(ei[0]), (ei[0], ei[1])))
     assert np.array_equal(mis_decode_np(pred, adj, device=dev), ref)
+
+
+def test_solve_tsp_pipeline(dev):
+    """k-NN -> sampling loop -> merge -> 2-opt end to end (pl_tsp_model.py:152-241) on a small instance with 3 parallel
+    samples: valid tours, 2-opt never lengthens a merged tour, the best cost is the minimum."""
+    from difusco_amd import TSPModel
+    from difusco_amd.pipeline import solve_tsp, tour_length
+    from oracle import difusco_oracle as O
+    p = O.init_params(64, 2, 2, seed=0)
+    pts = np.random.default_rng(4).random((80, 2))
+    args = dict(diffusion_type="categorical", diffusion_schedule="linear", diffusion_steps=1000, sparse_factor=10,
+                n_layers=2, hidden_dim=64, inference_trick="ddim", inference_diffusion_steps=10, inference_schedule="cosine")
+    m = TSPModel(args, p, device=dev, seed=3)
+    timings = {}
+    tour, cost, costs, info = solve_tsp(m, pts, sparse_factor=10, parallel_sampling=3, two_opt_iterations=200, timings=timings)
+    assert sorted(tour[:-1]) == list(range(80)) and tour[0] == tour[-1] == 0
+    assert abs(tour_length(pts, tour) - cost) < 1e-12 and cost == min(costs) and len(costs) == 3
+    assert all(c <= mc + 1e-9 for c, mc in zip(costs, info["merged_costs"]))
+    assert set(timings) == {"knn", "sampling", "merge", "two_opt"}
