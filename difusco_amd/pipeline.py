@@ -56,3 +56,32 @@ def solve_tsp(model, points: np.ndarray, sparse_factor: int, parallel_sampling: 
     best = int(np.argmin(costs))
     return solved[best].tolist(), costs[best], costs, {"merge_iterations": merge_iterations, "two_opt_iterations": ns,
                                                        "merged_costs": [tour_length(pts64, t) for t in tours]}
+
+
+def solve_mis(model, n_nodes: int, edge_index, parallel_sampling: int = 1, generator: Optional[torch.Generator] = None,
+              timings: Optional[Dict[str, float]] = None):
+    """``MISModel.test_step`` (``difusco/pl_mis_model.py:142-206``): ``parallel_sampling`` noise samples of ONE graph
+    through the denoising loop (disjoint union), greedy decode of every sample, best = largest set.  ``edge_index``:
+    int64 [2,E] in the dataset's layout (both directions + self loops).  Returns (best 0/1 array, best size, sizes)."""
+    from .decode import mis_decode_np
+    dev = model.device
+    ei = edge_index if isinstance(edge_index, torch.Tensor) else torch.from_numpy(np.asarray(edge_index))
+    ei = ei.to(dev)
+
+    def tick(name, t0):
+        if timings is not None:
+            torch.cuda.synchronize(dev)
+            timings[name] = timings.get(name, 0.0) + time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    model.args.parallel_sampling = parallel_sampling
+    ei_rep = model.duplicate_edge_index(ei, n_nodes, dev) if parallel_sampling > 1 else ei        # pl_mis_model.py:168-169
+    scores = model.sample(n_nodes * parallel_sampling, ei_rep, generator=generator)               # :171-192
+    tick("sampling", t0)
+    t0 = time.perf_counter()
+    graph = model.prepare_graph(ei_rep, n_nodes * parallel_sampling)
+    sol = mis_decode_np(scores, graph=graph, device=dev).reshape(parallel_sampling, n_nodes)      # :195-196, one call
+    tick("decode", t0)
+    sizes = sol.sum(axis=1)
+    best = int(np.argmax(sizes))
+    return sol[best], int(sizes[best]), sizes.tolist()
