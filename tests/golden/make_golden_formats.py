@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Fixture for the MCTS heatmap text: runs the REFERENCE's tsp_mcts/convert_numpy_to_txt.py `main` (imported from
+/root/reference with a placeholder for the absent `fire` CLI package, which only its __main__ block uses, and with
+`np.bool` - removed in numpy >= 1.24 - aliased to `bool` for the duration of the call) on small dense heatmaps written
+in the reference's own .npy naming.  Build container only.  Stores inputs and the produced text."""
+import importlib.util
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.modules.setdefault("fire", types.ModuleType("fire"))
+spec = importlib.util.spec_from_file_location("ref_convert", "/root/reference/tsp_mcts/convert_numpy_to_txt.py")
+ref = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(ref)
+
+for name, n, prob, seed in [("n30", 30, 0.1, 1), ("n64", 64, 0.02, 2)]:
+    rng = np.random.default_rng(seed)
+    pts = rng.random((n, 2)).astype(np.float32)
+    heat = (rng.random((n, n)) ** 4).astype(np.float32)
+    heat[rng.random((n, n)) < 0.6] = 0.0
+    tmp = tempfile.mkdtemp(prefix="difusco_fmt_")
+    os.makedirs(os.path.join(tmp, "numpy_heatmap"))
+    np.save(os.path.join(tmp, "numpy_heatmap", "test-heatmap-0.npy"), heat)
+    np.save(os.path.join(tmp, "numpy_heatmap", "test-points-0.npy"), pts)
+    had = hasattr(np, "bool")
+    if not had:
+        np.bool = bool
+    try:
+        ref.main(tmp, os.path.join(tmp, "out"), num_nodes=n, num_files=1, expected_valid_prob=prob)
+    finally:
+        if not had:
+            del np.bool
+    text = open(os.path.join(tmp, "out", "heatmap", f"tsp{n}", f"heatmaptsp{n}_0.txt")).read()
+    np.savez_compressed(os.path.join(HERE, f"mcts_text_{name}.npz"), heat=heat, points=pts, num_nodes=np.int64(n),
+                        expected_valid_prob=np.float64(prob), text=np.frombuffer(text.encode(), dtype=np.uint8),
+                        provenance="reference: tsp_mcts/convert_numpy_to_txt.main (fire placeholder, np.bool alias)")
+    print(name, len(text), "chars")

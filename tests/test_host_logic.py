@@ -245,3 +245,23 @@ def test_knn_generator_matches_sklearn_fixture(golden_dir):
         n = z["points"].shape[0]
         assert np.array_equal(ei[0], np.repeat(np.arange(n), k))
         assert np.array_equal(ei[1].reshape(n, k), z["idx_knn"])
+
+
+def test_mcts_heatmap_text_matches_reference(golden_dir, tmp_path):
+    """difusco_amd.formats against the text the reference's convert_numpy_to_txt.py produced (make_golden_formats.py)."""
+    import glob
+    from difusco_amd import formats
+    paths = sorted(glob.glob(os.path.join(golden_dir, "mcts_text_*.npz")))
+    assert len(paths) >= 2
+    for p in paths:
+        z = np.load(p)
+        n, prob = int(z["num_nodes"]), float(z["expected_valid_prob"])
+        text = formats.mcts_heatmap_text(z["heat"], z["points"], n, prob)
+        assert text == bytes(z["text"]).decode()
+        out = formats.write_mcts_heatmap(z["heat"], z["points"], n, str(tmp_path), 0, expected_valid_prob=prob)
+        assert out.endswith(f"heatmap/tsp{n}/heatmaptsp{n}_0.txt") and open(out).read() == text
+    hp, pp = formats.save_numpy_heatmap(z["heat"], z["points"], str(tmp_path), 3)
+    assert hp.endswith("numpy_heatmap/test-heatmap-3.npy") and np.array_equal(np.load(hp), z["heat"])
+    ei = np.array([[0, 1, 2], [1, 2, 0]])
+    d = formats.densify(np.array([0.5, 0.25, 1.0]), ei, 3)
+    assert d[0, 1] == 0.5 and d[2, 0] == 1.0 and d.sum() == 1.75
