@@ -114,13 +114,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  (ABL & 1024):
-  // give every XCD one contiguous range of tiles, so the node-table rows its tiles gather stay in its L2.
-  int bid = blockIdx.x;
-  if constexpr ((ABL & 1024) != 0) {
-    const int nblk = gridDim.x, per = nblk >> 3, rem = nblk & 7, x = bid & 7;
-    bid = x * per + (x < rem ? x : rem) + (bid >> 3);
-  }
+  const int bid = blockIdx.x;
   const int tile = bid * WAVES + wave;
   const int s_raw = tile * 32 + l31;
   const bool valid = s_raw < n_edges;
@@ -134,44 +128,22 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
   // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
   unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define FUSED_STAMP(k)                                                       \
-  if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();     \
-  if constexpr ((ABL & 512) != 0) {   /* experiment: matrix phases at raised issue priority */ \
-    if ((k) == 1 || (k) == 6) __builtin_amdgcn_s_setprio(1);                  \
-    if ((k) == 4 || (k) == 9) __builtin_amdgcn_s_setprio(0);                  \
-  }
+#define FUSED_STAMP(k) \
+  if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();
   FUSED_STAMP(0)
 
   // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}] = two float4 of the tiled
   // layout = 2 KiB per wave and slab, cold HBM reads.
-  //  * production: a register ring, RING slabs ahead of the MFMAs.
-  //  * (ABL & 4096, 4-wave geometry, experiment): LDS-DMA into the wave's own aggregation scratch, which is idle
-  //    during GEMM 1: slab ks+2 is requested in iteration ks and must have landed at the end of iteration ks+1 (see
-  //    FUSED_PIPE_END), each lane reads its own 16 bytes back.  Measured 2.5 % slower than the register ring
-  //    (0.942 vs 0.919 ms per layer): the extra LDS round trip costs more than the 16 registers it frees.
+  // A register ring, RING slabs ahead of the MFMAs.  (Routing this stream through LDS-DMA into the idle aggregation
+  // scratch was measured 2.5 % slower - profiles/r01/fused_kernel_study.txt - and removed.)
   constexpr bool kDma = (ABL & 2048) == 0;                          // weight stages by LDS-DMA (else registers)
   // profiling only (wrong results): matrix phases without stage refills and barriers / without the e stream
   constexpr bool kNoSync = (ABL & 16384) != 0, kNoE = (ABL & 32768) != 0;
-  constexpr bool kDmaE = kDma && SPS == 1 && (ABL & 4096) != 0;     // e stream by LDS-DMA too (experiment)
   static_assert(kDma || !G_::ALIAS, "geometry 40 has no register-staged variant");
   constexpr int RING = kDma ? 2 : 4;   // beside LDS-DMA staging every load is drained at the stage barrier
   v4f er[RING][2];
-  // (buffer addressing: SGPR resource + 32-bit lane offset + SGPR/immediate offsets - no per-lane 64-bit pointers;
-  //  the instruction's immediate offset is added to the memory address AND to the LDS address)
-  const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(etile, 0, 32 * H * 4, 0x00020000);
-#define FUSED_DMA_E(ks)                                                                                      \
-  {                                                                                                          \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                \
-        rs_e, (__attribute__((address_space(3))) void*)(scr + ((ks) & 1) * 512), 16, loff * 4, (ks) * 2048, 0, 0);      \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                \
-        rs_e, (__attribute__((address_space(3))) void*)(scr + ((ks) & 1) * 512), 16, loff * 4, (ks) * 2048, 1024,       \
-        0);                                                                                                  \
-  }
   if constexpr (L0) {
     // no e stream
-  } else if constexpr (kDmaE) {
-    FUSED_DMA_E(0)
-    FUSED_DMA_E(1)
   } else {
 #pragma unroll
     for (int d = 0; d < RING; ++d) {
@@ -279,8 +251,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #define FUSED_PIPE_END(t)                                                        \
   if (!kNoSync && (t) + 1 < NSTAGE) {                                            \
     if constexpr (kDma) {                                                        \
-      if (kDmaE && !L0 && (t) + 2 < 16) __builtin_amdgcn_s_waitcnt(0x0F72); /* vmcnt(2) */ \
-      else __builtin_amdgcn_s_waitcnt(0x0F70);                       /* vmcnt(0) */ \
+      __builtin_amdgcn_s_waitcnt(0x0F70);                            /* vmcnt(0) */ \
     }                                                                            \
     __syncthreads();                                                             \
   }
@@ -341,9 +312,6 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       if constexpr (L0) {
         c0 = *reinterpret_cast<const v4f*>(prm + l0_row + 16 * ks + 4 * hh);
         c1 = *reinterpret_cast<const v4f*>(prm + l0_row + 16 * ks + 8 + 4 * hh);
-      } else if constexpr (kDmaE) {
-        c0 = *reinterpret_cast<const v4f*>(scr + (ks & 1) * 512 + loff);
-        c1 = *reinterpret_cast<const v4f*>(scr + ((ks & 1) * 512 + 256) + loff);
       } else {
         c0 = er[ks % RING][0];
         c1 = er[ks % RING][1];
@@ -354,13 +322,6 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       split8<T>(xs, xh[sub], xl[sub]);
-      if constexpr (kDmaE && !L0) {   // the slot is free once its values sit in registers: request slab ks + 2 into it
-        if (ks + 2 < 16) {
-          __builtin_amdgcn_sched_barrier(0);
-          FUSED_DMA_E(ks + 2)
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
     }
     // 8 SPS weight blocks (bi = sub * 8 + nb), A fragments read from LDS two blocks ahead of their MFMAs
     const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
@@ -643,7 +604,6 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #undef FUSED_PIPE_BEGIN
 #undef FUSED_PIPE_END
 #undef FUSED_DMA_STAGE
-#undef FUSED_DMA_E
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -751,10 +711,7 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     case 4: return launch_fused_t<FFp16, 4, FUSED_NW>(FUSED_ARGS);
     case 128: return launch_fused_t<FFp16, 128, FUSED_NW>(FUSED_ARGS);
     case 256: return launch_fused_t<FFp16, 256, FUSED_NW>(FUSED_ARGS);
-    case 512: return launch_fused_t<FFp16, 512, FUSED_NW>(FUSED_ARGS);
-    case 1024: return launch_fused_t<FFp16, 1024, FUSED_NW>(FUSED_ARGS);
     case 2048: return launch_fused_t<FFp16, 2048, FUSED_NW>(FUSED_ARGS);
-    case 4096: return launch_fused_t<FFp16, 4096, FUSED_NW>(FUSED_ARGS);
     case 140: return launch_fused_t<FFp16, 0, 40>(FUSED_ARGS);                 // geometry 40: 4 waves, 32 KiB stages
     case 155: return launch_fused_t<FFp16, 15, 40>(FUSED_ARGS);
     case 16399: return launch_fused_t<FFp16, 16399, FUSED_NW>(FUSED_ARGS);   // 15 + no stage refills / barriers
