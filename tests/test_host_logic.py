@@ -265,3 +265,44 @@ def test_mcts_heatmap_text_matches_reference(golden_dir, tmp_path):
     ei = np.array([[0, 1, 2], [1, 2, 0]])
     d = formats.densify(np.array([0.5, 0.25, 1.0]), ei, 3)
     assert d[0, 1] == 0.5 and d[2, 0] == 1.0 and d.sum() == 1.75
+
+
+def test_step_argument_validation_without_gpu():
+    """difusco_denoise_step validates its argument block before any HIP call: every malformed block comes back as
+    DIFUSCO_EINVAL with a message (the reference raises Python exceptions; the binding turns codes into exceptions)."""
+    import ctypes
+    from difusco_amd import _lib
+    L = _lib.lib()
+
+    def make(**kw):
+        a = _lib.StepArgs()
+        a.struct_size, a.abi_version = ctypes.sizeof(_lib.StepArgs), _lib.ABI_VERSION
+        a.hidden, a.n_layers, a.out_channels, a.task = 256, 12, 2, _lib.TASK_TSP
+        a.diffusion, a.n_nodes, a.n_edges, a.n_segments = _lib.CATEGORICAL, 10, 20, 1
+        for name in ("weights", "rowptr", "col", "xt", "xt_out", "workspace", "points"):
+            setattr(a, name, 0x1000)            # never dereferenced: validation fails first
+        a.precision = _lib.PRECISIONS["fp16x3"]
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    def expect_einval(a, fragment):
+        rc = L.difusco_denoise_step(ctypes.byref(a))
+        assert rc < 0, fragment
+        assert fragment in L.difusco_last_error().decode(), L.difusco_last_error().decode()
+
+    assert L.difusco_denoise_step(None) < 0
+    expect_einval(make(struct_size=8), "ABI mismatch")
+    expect_einval(make(abi_version=_lib.ABI_VERSION - 1), "ABI mismatch")
+    expect_einval(make(hidden=100), "hidden must be")
+    expect_einval(make(n_layers=0), "n_layers")
+    expect_einval(make(task=7), "unknown task")
+    expect_einval(make(out_channels=1), "out_channels")
+    expect_einval(make(n_nodes=0), "n_nodes")
+    expect_einval(make(xt=None), "null device pointer")
+    expect_einval(make(points=None), "TSP needs points")
+    expect_einval(make(n_segments=3), "seg_ptr required")
+    expect_einval(make(gn_phase=3), "gn_phase")
+    expect_einval(make(gn_phase=1), "gn_sums")
+    with pytest.raises(_lib.DifuscoHipError):
+        _lib.check(L.difusco_denoise_step(ctypes.byref(make(hidden=100))))
