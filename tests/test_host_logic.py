@@ -306,3 +306,26 @@ def test_step_argument_validation_without_gpu():
     expect_einval(make(gn_phase=1), "gn_sums")
     with pytest.raises(_lib.DifuscoHipError):
         _lib.check(L.difusco_denoise_step(ctypes.byref(make(hidden=100))))
+
+
+def test_decode_entry_points_reject_bad_arguments_without_gpu():
+    import ctypes
+    from difusco_amd import _lib
+    L = _lib.lib()
+    nbytes = ctypes.c_size_t()
+    it, ok = ctypes.c_int64(), ctypes.c_int32()
+    p = ctypes.c_void_p(0x1000)
+    assert L.difusco_tsp_merge_tour(2, 10, p, p, p, p, p, 1 << 20, p, ctypes.byref(it), ctypes.byref(ok), None) < 0
+    assert "n_nodes >= 3" in L.difusco_last_error().decode()
+    assert L.difusco_tsp_merge_tour(10, 10, p, None, p, p, p, 1 << 20, p, ctypes.byref(it), ctypes.byref(ok), None) < 0
+    assert L.difusco_tsp_two_opt_workspace_bytes(3, 1, ctypes.byref(nbytes)) < 0
+    assert L.difusco_tsp_two_opt(3, 1, p, p, 10, p, 1 << 20, ctypes.byref(it), None) < 0
+    assert L.difusco_tsp_two_opt_workspace_bytes(1000, 4, ctypes.byref(nbytes)) == 0 and nbytes.value > 4 * 1001 * 16
+    assert L.difusco_tsp_two_opt(1000, 4, p, p, 10, p, 16, ctypes.byref(it), None) < 0          # workspace too small
+    assert L.difusco_knn_graph_workspace_bytes(10, 11, ctypes.byref(nbytes)) < 0                  # k > n
+    assert L.difusco_knn_graph_workspace_bytes(10, 0, ctypes.byref(nbytes)) < 0
+    assert L.difusco_knn_graph_workspace_bytes(5000, 2000, ctypes.byref(nbytes)) < 0              # k > 1024
+    assert L.difusco_knn_graph_workspace_bytes(20000, 50, ctypes.byref(nbytes)) == 0 and nbytes.value == 1024 * 20000 * 8
+    assert L.difusco_knn_graph(10, 11, p, 0, p, p, None, 0, None) < 0
+    assert L.difusco_mis_decode(0, p, p, p, p, p, 1 << 20, None, None) < 0
+    assert L.difusco_mis_decode_workspace_bytes(0, ctypes.byref(nbytes)) < 0
