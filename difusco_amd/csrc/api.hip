@@ -110,7 +110,7 @@ Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk)
   w.tmp = (float*)take(sizeof(float) * (E > 2 ? E : 2) * H);
   w.tbias = (float*)take(sizeof(float) * L * H);
   w.table_in = (float*)take(sizeof(float) * 2 * H);
-  w.table = (float*)take(sizeof(float) * 2 * H);
+  w.table = (float*)take(sizeof(float) * 4 * H);      // rows 0,1: edge-input table; rows 2,3: C of layer 0 applied to them
   w.stats = (float*)take(sizeof(float) * S * 64);
   w.partial = (double*)take(sizeof(double) * (size_t)S * (nblk < 256 ? 256 : nblk) * 64);
   w.part = (float*)take(H == 256 ? sizeof(float) * fused_part_floats(E) : 0);
@@ -300,9 +300,11 @@ int difusco_denoise_step(const difusco_step_args* a) {
       PROF(PROF_EMBED, hipMemsetAsync(ws.e + (E / 32) * 32 * H, 0, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
     if (a->xt_is_binary) {
       PROF(PROF_EMBED, launch_scalar_embed(nullptr, nullptr, G(DIFUSCO_W_DIMT_SCALAR), 2, H, ws.table_in, st))
-      PROF(PROF_EMBED, linear_rows(ws.table_in, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.table,
-                                   2, H, H, H, st))
-      if (l0_fold) { /* e0 is read from ws.table by the first fused layer */ }
+      PROF(PROF_EMBED, launch_two_rows_linear(H, ws.table_in, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), ws.table,
+                                              st))
+      if (l0_fold) {   // e0 and C e0 are read from ws.table by the first fused layer: C on the two rows, exact fp32
+        PROF(PROF_EMBED, launch_two_rows_linear(H, ws.table, LW(0, DIFUSCO_WL_C_W), nullptr, ws.table + 2 * H, st))
+      }
       else if (fused) PROF(PROF_EMBED, launch_table_rows_tiled(a->xt, a->perm, ws.table, E, ws.e, st))
       else PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, ws.table, E, H, ws.e, st))
     } else {
@@ -322,7 +324,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
     PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
                                        H, H, H, st))
     if (l0_fold) {   // e = zeros (gnn_encoder.py:407) comes from an all-zero table; only the pad tail must read as zero
-      PROF(PROF_EMBED, hipMemsetAsync(ws.table, 0, sizeof(float) * 2 * H, st))
+      PROF(PROF_EMBED, hipMemsetAsync(ws.table, 0, sizeof(float) * 4 * H, st))
       PROF(PROF_EMBED, hipMemsetAsync(ws.e + (E / 32) * 32 * H, 0, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
     } else if (E > 0) {
       PROF(PROF_EMBED, hipMemsetAsync(ws.e, 0, sizeof(float) * (fused ? E_pad : E) * H, st))

@@ -43,7 +43,8 @@ namespace difusco {
 namespace fused {
 constexpr int H = 256;
 constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregation scratch (64 + 4 pad)
-enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT, P_TAB0, P_TAB1, P_COUNT };   // P_TAB*: layer-0 input table rows
+enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT, P_TAB0, P_TAB1, P_CE0, P_CE1, P_COUNT };
+// P_TAB*: layer-0 input table rows; P_CE*: C (weight of GEMM 1) applied to those rows
 
 // Workgroup geometry (template parameter NW of the kernel is a geometry code).  A workgroup is WAVES tiles of 32
 // edges; a weight stage holds ENT rows of 32 bytes per plane:
@@ -71,12 +72,12 @@ struct Geo {
   static constexpr int SPQ = 16 / KPS;          // GEMM 2: stages per output quarter
   static constexpr int NSTAGE = NS1 + 4 * SPQ;  // 16 | 32 | 16
   static constexpr int LDS_W = 2 * BUF * 2;     // bytes, double buffered             65536 | 32768 | 65536
-  static constexpr int LDS_P = P_COUNT * H * 4; // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O, table rows  9216
+  static constexpr int LDS_P = P_COUNT * H * 4; // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O, table rows (4) 11264
   static constexpr int LDS_S = WAVES * 32 * SCR_STRIDE * 4;   // bytes                69632 | 34816 | 34816
   // ALIAS: [buffer 0][buffer 1 = scratch ...][... scratch tail][parameters]; else [buffers][parameters][scratch]
   static constexpr int OFF_S = ALIAS ? BUF * 2 : LDS_W + LDS_P;
   static constexpr int OFF_P = ALIAS ? BUF * 2 + LDS_S : LDS_W;
-  static constexpr int LDS_TOTAL = ALIAS ? BUF * 2 + LDS_S + LDS_P : LDS_W + LDS_P + LDS_S;   // 144384 | 76800 | 76800
+  static constexpr int LDS_TOTAL = ALIAS ? BUF * 2 + LDS_S + LDS_P : LDS_W + LDS_P + LDS_S;   // 146432 | 78848 | 78848
   static_assert(!ALIAS || LDS_S >= BUF * 2, "the aliased scratch must cover stage buffer 1");
 };
 constexpr int geo_waves(int code) { return code == 8 ? 8 : 4; }
@@ -97,8 +98,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // head then needs no statistics pass over e (nn.py:93-100, gnn_encoder.py:400-401).
   // L0 (first layer of a step whose edge input is a table lookup): e_in[s] = l0_table[x > 0.5 ? 1 : 0] with
   // x = l0_x[l0_perm ? l0_perm[s] : s] (categorical TSP: the edge embedding of the bit x_t, gnn_encoder.py:395) or
-  // row 0 when l0_x is null (MIS: e = zeros, gnn_encoder.py:407).  The kernel then never reads e: the GEMM 1 operand
-  // and the residual come from the two table rows held in LDS, and the separate embedding pass over e disappears.
+  // row 0 when l0_x is null (MIS: e = zeros, gnn_encoder.py:407).  The kernel then never reads e, and it has no GEMM 1
+  // either: with only two distinct input rows, C e_in is one of two vectors (l0_table rows 2, 3 = C applied to rows 0,
+  // 1, computed once per step by an exact fp32 linear on two rows); the accumulators start from that row, the
+  // residual comes from the input row, and the separate embedding pass over e disappears.
   // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
   // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
   constexpr int ablate = ABL;
@@ -256,7 +259,9 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     __syncthreads();                                                             \
   }
 
-  if constexpr (kDma) { FUSED_DMA_STAGE(0) } else { FUSED_LOAD_STAGE(0) }
+  static_assert(!L0 || kDma, "the first-layer variant exists for the LDS-DMA staging only");
+  if constexpr (L0) { FUSED_DMA_STAGE(NS1) }           // no GEMM 1: the stage stream starts with GEMM 2
+  else if constexpr (kDma) { FUSED_DMA_STAGE(0) } else { FUSED_LOAD_STAGE(0) }
 
   // layer parameters -> LDS (thread = feature)
   if (tid < H) {
@@ -270,6 +275,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     if constexpr (L0) {
       prm[P_TAB0 * H + tid] = l0_table[tid];
       prm[P_TAB1 * H + tid] = l0_table[H + tid];
+      prm[P_CE0 * H + tid] = l0_table[2 * H + tid];
+      prm[P_CE1 * H + tid] = l0_table[3 * H + tid];
     }
   }
   // layer 0: this lane's table row (float offset into prm), rule of table_rows_tiled_kernel
@@ -292,16 +299,28 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 
   FUSED_STAMP(1)
   v16f acc1[8];
+  if constexpr (L0) {      // C e_in of this lane's features, from the row that belongs to its input row
+    const int ce_row = l0_row + (P_CE0 - P_TAB0) * H;
 #pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
+    for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.0f;
+      for (int g = 0; g < 4; ++g) {
+        const v4f c = *reinterpret_cast<const v4f*>(prm + ce_row + 32 * nb + 8 * g + 4 * hh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc1[nb][4 * g + q] = c[q];
+      }
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.0f;
+  }
 
   const int a_off = wslot(l31, hh);   // entry = 32 nb + l31 : (entry >> 3) & 1 == (l31 >> 3) & 1
 
   // ================================ GEMM 1 ==========================================================
 #pragma unroll
-  for (int t = 0; t < NS1; ++t) {
+  for (int t = 0; t < (L0 ? 0 : NS1); ++t) {
     FUSED_PIPE_BEGIN(t)
     // B operands of the slab(s) of this stage
     frag xh[SPS], xl[SPS];
@@ -309,10 +328,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     for (int sub = 0; sub < SPS; ++sub) {
       const int ks = SPS * t + sub;
       v4f c0, c1;
-      if constexpr (L0) {
-        c0 = *reinterpret_cast<const v4f*>(prm + l0_row + 16 * ks + 4 * hh);
-        c1 = *reinterpret_cast<const v4f*>(prm + l0_row + 16 * ks + 8 + 4 * hh);
-      } else {
+      {
         c0 = er[ks % RING][0];
         c1 = er[ks % RING][1];
         if (!kNoE && ks + RING < 16) {

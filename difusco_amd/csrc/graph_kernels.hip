@@ -690,6 +690,37 @@ hipError_t launch_table_rows_tiled(const float* x, const int* perm, const float*
   return hipGetLastError();
 }
 
+// y[r][f] = b[f] + sum_k W[f][k] x[r][k] for r = 0, 1 (the two rows of the layer-0 tables): one wavefront per output
+// feature, lanes over k, fp32 fma chain per lane + wave reduction.  A [2 x H] problem is far below what the MFMA row
+// kernels are built for (their fixed cost is ~50 us); this takes a few microseconds.
+template <int VEC>
+__global__ __launch_bounds__(256) void two_rows_linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y) {
+  constexpr int H = 64 * VEC;
+  const int lane = threadIdx.x & 63, f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= H) return;
+  float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int k = lane * VEC + v;
+    const float wv = w[(long long)f * H + k];
+    a0 = fmaf(wv, x[k], a0);
+    a1 = fmaf(wv, x[H + k], a1);
+  }
+  wave_sum2(a0, a1);
+  if (lane == 0) {
+    const float b = bias ? bias[f] : 0.0f;
+    y[f] = a0 + b;
+    y[H + f] = a1 + b;
+  }
+}
+
+hipError_t launch_two_rows_linear(int H, const float* x, const float* w, const float* bias, float* y, hipStream_t stream) {
+  dim3 grid((unsigned)(H / 4));
+  DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((two_rows_linear_kernel<VEC>), grid, dim3(256), 0, stream, x, w, bias, y))
+  return hipGetLastError();
+}
+
 // GroupNorm + conv + posterior on the tiled e buffer (one statistic segment = the whole call).
 // partial must hold nblk*64 doubles, nblk a multiple of 8.
 hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk, double* partial, float* stats,

@@ -62,6 +62,8 @@ hipError_t launch_time_bias(float t, int H, int n_layers, const float* freqs, co
 hipError_t launch_pos_embed(const float* points, const float* dimt, int n_nodes, int H, float* out, hipStream_t stream);
 hipError_t launch_scalar_embed(const float* x, const int* perm, const float* dimt, long long rows, int H, float* out,
                                hipStream_t stream);
+// y[2][H] = x[2][H] W^T + b for the two-row layer-0 tables (tiny: one wavefront per output feature)
+hipError_t launch_two_rows_linear(int H, const float* x, const float* w, const float* bias, float* y, hipStream_t stream);
 hipError_t launch_table_rows(const float* x, const int* perm, const float* table, long long rows, int H, float* out,
                              hipStream_t stream);
 hipError_t launch_table_rows_tiled(const float* x, const int* perm, const float* table, long long rows, float* out,
