@@ -274,9 +274,11 @@ int difusco_denoise_step(const difusco_step_args* a) {
   const int64_t E_pad = (E + 255) / 256 * 256;
   // first layer: when the edge input is a table lookup (categorical TSP: embedding of the bit; MIS: zeros) the fused
   // kernel takes it from the table and the pass that would write e0 to HBM is skipped
-  // last layer (TSP, at least two layers): the fused kernel also emits the head's GroupNorm partial sums per tile
-  const bool gn_fold = fused && tsp && L >= 2 && difusco::g_fused_gn_fold != 0 && difusco::g_fused_variant == 0 &&
-                       difusco::g_fused_ablate == 0;
+  // last layer (at least two layers).  TSP: the fused kernel also emits the head's GroupNorm partial sums per tile and
+  // skips the node update nobody reads; MIS: it skips the edge output nobody reads.
+  const bool tail_fold = fused && L >= 2 && difusco::g_fused_gn_fold != 0 && difusco::g_fused_variant == 0 &&
+                         difusco::g_fused_ablate == 0;
+  const bool gn_fold = tail_fold && tsp;
   const bool l0_fold = fused && difusco::g_fused_l0_fold != 0 && difusco::g_fused_variant == 0 &&
                        difusco::g_fused_ablate == 0 && (tsp ? a->xt_is_binary != 0 : true);
 
@@ -352,9 +354,9 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                       LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                       LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
                                       ws.table, tsp ? a->xt : nullptr, tsp ? a->perm : nullptr, st))
-    } else if (fused && gn_fold && l == L - 1) {
+    } else if (fused && tail_fold && l == L - 1) {
       PROF(PROF_LINEAR_EDGE,
-           launch_edge_layer_fused_gn(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,
+           launch_edge_layer_fused_tail(a->precision, tsp ? 1 : 2, ws.e, ws.node4, a->row, a->col, (int)E,
                                       reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_C_PLANES)) + split_off,
                                       reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_OUT_PLANES)) + split_off,
                                       (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
@@ -371,6 +373,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                    LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
                                    st))
     }
+    if (fused && gn_fold && l == L - 1) continue;     // TSP: h is not read after the last layer
     if (fused) {
       PROF(PROF_GATE, launch_node_finalize((int)N, (int)E, a->rowptr, ws.node4, ws.part, ws.direct, ws.h,
                                            LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),

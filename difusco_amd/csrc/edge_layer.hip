@@ -83,7 +83,7 @@ struct Geo {
 constexpr int geo_waves(int code) { return code == 8 ? 8 : 4; }
 }  // namespace fused
 
-template <typename T, int ABL, int NW, bool L0, bool GNP>
+template <typename T, int ABL, int NW, bool L0, bool GNP, int TAIL>
 __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused_kernel(
     float* e, const float* __restrict__ node4, const int* __restrict__ row, const int* __restrict__ col, int n_edges,
     const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
@@ -93,6 +93,11 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     unsigned long long* dbg,     // dbg: optional phase timestamps (profiling), nullptr in production
     const float* __restrict__ l0_table, const float* __restrict__ l0_x, const int* __restrict__ l0_perm,
     float* __restrict__ gn_tile) {
+  // TAIL: what the step still needs from this layer.  0 = everything.  1 = last layer of a TSP step: the head reads
+  // only e, so the node update is dead work - no V h gathers, no gate, no neighbour sum (the caller skips
+  // node_finalize).  2 = last layer of a MIS step: the head reads only h, so the edge output is dead work - the kernel
+  // ends after the neighbour sum (no LayerNorms, no GEMM 2, no store of e).  The reference computes both and discards
+  // them (gnn_encoder.py:400-401 / :412-413 read one of the two states).
   // GNP (last layer of a step whose head reads e): per tile and GroupNorm group (8 channels = the two lane halves of
   // one (quarter, block, quad)), the sum and the sum of squares of the NEW e values go to gn_tile[tile][32][2]; the
   // head then needs no statistics pass over e (nn.py:93-100, gnn_encoder.py:400-401).
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       const int fb_ = 32 * ((b) >> 1) + 8 * (2 * ((b) & 1) + q2) + 4 * hh;            \
       if constexpr (!(ablate & 1) && !(ablate & 256)) {                               \
         ga[buf][q2][0] = *reinterpret_cast<const v4f*>(nj + 2 * H + fb_);             \
-        ga[buf][q2][2] = *reinterpret_cast<const v4f*>(nj + H + fb_);                 \
+        if constexpr (TAIL != 1) ga[buf][q2][2] = *reinterpret_cast<const v4f*>(nj + H + fb_); \
       } else {                                                                        \
         ga[buf][q2][0] = ga[buf][q2][2] = v4f{0.f, 0.f, 0.f, 0.f};                    \
       }                                                                               \
@@ -415,11 +420,11 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
         const float ev = (ah[q] + bh[q]) + ce;
         acc1[nb][4 * g + q] = ev;
         s1 += ev;
-        m[q] = valid ? fast_sigmoid(ev) * vh[q] : 0.0f;   // (select, not multiply: pad lanes may hold anything)
+        if constexpr (TAIL != 1) m[q] = valid ? fast_sigmoid(ev) * vh[q] : 0.0f;   // (select: pad lanes may hold anything)
       }
-      *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
+      if constexpr (TAIL != 1) *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
     }
-    if ((b & 3) == 3) {
+    if (TAIL != 1 && (b & 3) == 3) {
       // 64 features (blocks 2 rnd, 2 rnd + 1) of all 32 edges are in the scratch: segmented column sums,
       // lane = feature 64 rnd + lane.  The first segment of a tile may continue from the previous tile and
       // the last into the next one (part[tile][0|1]); inner segments are complete (direct[node]).
@@ -449,6 +454,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   }
 #undef FUSED_GATHER
   FUSED_STAMP(5)
+  if constexpr (TAIL == 2) return;      // the edge output of this layer is never read
 
   // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
   constexpr float inv_h = 1.0f / 256.0f;
@@ -677,11 +683,12 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 int g_fused_ablate = 0;   // profiling knob (difusco_debug_set), 0 in production
 int g_fused_lds_pad = 0;  // profiling only (difusco_debug_set key 6)
-int g_fused_gn_fold = 1;  // 1: the last layer emits the head's GroupNorm partial sums (difusco_debug_set key 4)
+int g_fused_gn_fold = 1;  // 1: last-layer variants - TSP: GroupNorm partial sums + no node update; MIS: no edge
+                          //    output (difusco_debug_set key 4)
 int g_fused_l0_fold = 1;  // 1: the first layer reads its edge input from the 2-row table (difusco_debug_set key 3)
 unsigned long long* g_fused_dbg = nullptr;   // profiling: device buffer for phase timestamps, [n_tiles][8]
 
-template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false>
+template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0>
 static hipError_t launch_fused_t(float* e, const float* node4, const int* row, const int* col, int n_edges,
                                  const unsigned short* c_planes, const unsigned short* o_planes, long long plane_stride,
                                  const float* b_c, const float* g_e, const float* b_e, const float* tbias,
@@ -690,7 +697,7 @@ static hipError_t launch_fused_t(float* e, const float* node4, const int* row, c
                                  const float* l0_x = nullptr, const int* l0_perm = nullptr, float* gn_tile = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0, GNP>),
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er != hipSuccess) return er;
     attr_set = true;
@@ -698,7 +705,7 @@ static hipError_t launch_fused_t(float* e, const float* node4, const int* row, c
   constexpr int WV = fused::geo_waves(NW);
   const unsigned grid = (unsigned)((n_edges + 32 * WV - 1) / (32 * WV));
   // profiling: g_fused_lds_pad extra bytes of dynamic LDS lower the number of co-resident workgroups per CU
-  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP>), dim3(grid), dim3(64 * WV),
+  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL>), dim3(grid), dim3(64 * WV),
                      fused::Geo<NW>::LDS_TOTAL + g_fused_lds_pad, stream,
                      e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
                      time_on_edge, part, direct, g_fused_dbg, l0_table, l0_x, l0_perm, gn_tile);
@@ -740,22 +747,22 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
 #undef FUSED_ARGS
 }
 
-// Last layer of a step whose head normalises e (TSP): as launch_edge_layer_fused, plus the per-tile GroupNorm partial
-// sums gn_tile[ceil(n_edges / 32)][32][2] of the new edge state (see the GNP notes in the kernel).
-hipError_t launch_edge_layer_fused_gn(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
-                                      const unsigned short* c_planes, const unsigned short* o_planes,
-                                      long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
-                                      const float* tbias, const float* g_o, const float* b_o, const float* b_out,
-                                      int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream) {
+// Last layer of a step.  tail 1 (TSP: the head normalises e): the per-tile GroupNorm partial sums
+// gn_tile[ceil(n_edges / 32)][32][2] of the new edge state are emitted and the node update is skipped (no
+// node_finalize after it).  tail 2 (MIS: the head reads h): the kernel stops after the neighbour sum, e is not updated.
+hipError_t launch_edge_layer_fused_tail(int mode, int tail, float* e, const float* node4, const int* row, const int* col,
+                                        int n_edges, const unsigned short* c_planes, const unsigned short* o_planes,
+                                        long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
+                                        const float* tbias, const float* g_o, const float* b_o, const float* b_out,
+                                        int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream) {
   if (n_edges <= 0) return hipSuccess;
-  if (mode == 1)
-    return launch_fused_t<FBf16, 0, FUSED_NW, false, true>(e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c,
-                                                           g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, part, direct, stream,
-                                                           nullptr, nullptr, nullptr, gn_tile);
-  if (mode == 3)
-    return launch_fused_t<FFp16, 0, FUSED_NW, false, true>(e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c,
-                                                           g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, part, direct, stream,
-                                                           nullptr, nullptr, nullptr, gn_tile);
+#define TAIL_ARGS e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, \
+                  time_on_edge, part, direct, stream, nullptr, nullptr, nullptr, gn_tile
+  if (tail == 1 && mode == 1) return launch_fused_t<FBf16, 0, FUSED_NW, false, true, 1>(TAIL_ARGS);
+  if (tail == 1 && mode == 3) return launch_fused_t<FFp16, 0, FUSED_NW, false, true, 1>(TAIL_ARGS);
+  if (tail == 2 && mode == 1) return launch_fused_t<FBf16, 0, FUSED_NW, false, false, 2>(TAIL_ARGS);
+  if (tail == 2 && mode == 3) return launch_fused_t<FFp16, 0, FUSED_NW, false, false, 2>(TAIL_ARGS);
+#undef TAIL_ARGS
   return hipErrorInvalidValue;
 }
 

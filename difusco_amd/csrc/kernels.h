@@ -37,11 +37,11 @@ hipError_t launch_edge_layer_fused_l0(int mode, float* e, const float* node4, co
                                       int time_on_edge, float* part, float* direct, const float* table, const float* x,
                                       const int* perm, hipStream_t stream);
 extern int g_fused_l0_fold;
-hipError_t launch_edge_layer_fused_gn(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
-                                      const unsigned short* c_planes, const unsigned short* o_planes,
-                                      long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
-                                      const float* tbias, const float* g_o, const float* b_o, const float* b_out,
-                                      int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream);
+hipError_t launch_edge_layer_fused_tail(int mode, int tail, float* e, const float* node4, const int* row, const int* col,
+                                        int n_edges, const unsigned short* c_planes, const unsigned short* o_planes,
+                                        long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
+                                        const float* tbias, const float* g_o, const float* b_o, const float* b_out,
+                                        int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream);
 extern int g_fused_gn_fold;
 extern int g_fused_lds_pad;
 // software-pipelined persistent variant of the same layer (edge_layer_pipe.hip); same arguments and results
