@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--graphs-per-gpu", type=int, default=None, help="override the workload's graphs per GPU")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (0 = skip cpu_baseline)")
     ap.add_argument("--no-profile", action="store_true", help="skip the in-library HIP-event brackets")
+    ap.add_argument("--profile-all", action="store_true", help="bracket every kernel launch (full per-kernel table in the JSON; "
+                    "costs ~2.7 %% of a step) instead of the dominant kernel only")
     ap.add_argument("--no-fusion", action="store_true", help="unfused kernel sequence (A/B against the fused layer kernel)")
     ap.add_argument("--no-l0-fold", action="store_true", help="A/B: write the first layer's edge input to HBM as a separate "
                     "pass instead of reading it from the 2-row table inside the fused kernel")
@@ -220,7 +222,7 @@ def main():
         xt = one_step(i, xt)
     NCAT = 5
     if not args.no_profile:
-        _lib.check(_lib.lib().difusco_profile_enable(1, args.steps * (4 * LAYERS + 16)))
+        _lib.check(_lib.lib().difusco_profile_enable(1 if args.profile_all else 2, args.steps * (4 * LAYERS + 16)))
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -310,6 +312,8 @@ def main():
                                             "frac": gate_bytes / g_s / 1e9 / PEAK_HBM_GBS, "bound": "hbm",
                                             "algorithmic_bytes_per_launch": gate_bytes},
                 }
+            out["kernels"]["profiled"] = ("every launch (--profile-all)" if args.profile_all else
+                                          "dominant kernel only; the other entries are empty (use --profile-all)")
             out["kernels"].update({
                 "head": {"ms_total": prof["ms"][3], "launches": prof["launches"][3]},
                 "embed_misc": {"ms_total": prof["ms"][4], "launches": prof["launches"][4]},

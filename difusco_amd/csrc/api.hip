@@ -127,6 +127,7 @@ Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk)
 enum { PROF_LINEAR_EDGE = 0, PROF_LINEAR_NODE, PROF_GATE, PROF_HEAD, PROF_EMBED, PROF_NCAT };
 struct Profiler {
   bool on = false;
+  bool dominant_only = false;   // bracket category 0 (the E-row / fused edge-layer launches) only
   std::vector<hipEvent_t> ev;   // pairs
   std::vector<int> cat;
   size_t used = 0;              // pairs in use
@@ -137,7 +138,7 @@ struct ProfScope {
   bool active;
   size_t slot;
   ProfScope(int category, hipStream_t s) : st(s), active(false), slot(0) {
-    if (!g_prof.on || g_prof.used * 2 + 2 > g_prof.ev.size()) return;
+    if (!g_prof.on || (g_prof.dominant_only && category != PROF_LINEAR_EDGE) || g_prof.used * 2 + 2 > g_prof.ev.size()) return;
     slot = g_prof.used++;
     g_prof.cat[slot] = category;
     active = hipEventRecord(g_prof.ev[2 * slot], st) == hipSuccess;
@@ -520,6 +521,7 @@ int difusco_profile_enable(int on, int max_launches) {
     g_prof.used = 0;
   }
   g_prof.on = on != 0;
+  g_prof.dominant_only = on == 2;   // 2: only the dominant category (0) is bracketed - the cheap mode bench.py uses
   return DIFUSCO_OK;
 }
 

@@ -265,7 +265,8 @@ int difusco_tsp_two_opt(int n_nodes, int batch, const double* points, int32_t* t
 /* ---- in-library profiler (bench.py): HIP events on the launch stream around every kernel launch of
  * difusco_denoise_step, summed per category.  Categories: 0 edge-row linear (rows = n_edges),
  * 1 node-row linear, 2 edge gate/aggregate, 3 head (GroupNorm+conv+posterior, 3 launches),
- * 4 embeddings / time features / memset.  enable(1, max) (re)arms and pre-creates the events;
+ * 4 embeddings / time features / memset.  enable(1, max) (re)arms and pre-creates the events; enable(2, max)
+ * brackets category 0 only (every bracket costs a few microseconds of dispatch gap: ~2.7 % of a step for all five);
  * collect() synchronises, fills ms[c] / launches[c] for c < 5, re-arms, returns brackets read. */
 #define DIFUSCO_PROFILE_CATEGORIES 5
 int difusco_profile_enable(int on, int max_launches);

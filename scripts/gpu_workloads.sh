@@ -2,7 +2,7 @@
 # bench.py over the four single-GPU workloads of BASELINE.json's configs (outputs under gpurun_out/)
 mkdir -p gpurun_out
 for w in tsp500 tsp1000 tsp10000 mis; do
-  timeout 600 python bench.py --workload $w --steps ${STEPS:-10} --warmup 2 --cpu-steps ${CPU_STEPS:-0} > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
+  timeout 600 python bench.py --workload $w --steps ${STEPS:-10} --warmup 2 --cpu-steps ${CPU_STEPS:-0} --profile-all > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
   echo "== $w rc=$?"; tail -c 600 gpurun_out/bench_$w.err | tail -3
   python - <<PY
 import json
