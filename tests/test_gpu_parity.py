@@ -469,7 +469,7 @@ def test_golden_tsp_sparse_precisions(dev, golden_dir, prec):
         print(f"{prec} golden step {i}: logits L_inf {_check_cat(z, i, out, logits, prob):.3e}")
 
 
-@pytest.mark.parametrize("prec", ["fp16x3", "fp16x3/unfused", "fp32"])
+@pytest.mark.parametrize("prec", ["fp16x3", "bf16x3", "fp16x3/unfused", "fp32"])
 def test_oracle_mis_full_width(dev, prec):
     from difusco_amd import MISModel
     H, Lyr, n = 256, 4, 120
