@@ -5,7 +5,8 @@ path.  The compute lives in ``lib/libdifusco_hip.so`` (hand-written HIP, C ABI i
 from .schedules import CategoricalDiffusion, GaussianDiffusion, InferenceSchedule  # noqa: F401
 
 __all__ = ["CategoricalDiffusion", "GaussianDiffusion", "InferenceSchedule", "TSPModel", "MISModel",
-           "DenoiseEngine", "build_csr"]
+           "DenoiseEngine", "build_csr", "knn_edge_index_gpu", "merge_tours", "batched_two_opt_torch", "mis_decode_np",
+           "solve_tsp", "solve_mis"]
 
 
 def __getattr__(name):  # heavy imports (ctypes library, torch) on first use
@@ -15,7 +16,13 @@ def __getattr__(name):  # heavy imports (ctypes library, torch) on first use
     if name == "DenoiseEngine":
         from .engine import DenoiseEngine
         return DenoiseEngine
-    if name in ("build_csr", "CsrGraph", "complete_graph_batch"):
+    if name in ("build_csr", "CsrGraph", "complete_graph_batch", "knn_edge_index_gpu"):
         from . import graph
         return getattr(graph, name)
+    if name in ("merge_tours", "batched_two_opt_torch", "mis_decode_np"):
+        from . import decode
+        return getattr(decode, name)
+    if name in ("solve_tsp", "solve_mis"):
+        from . import pipeline
+        return getattr(pipeline, name)
     raise AttributeError(name)

@@ -14,7 +14,6 @@ import torch
 import torch.distributed as dist
 
 from .weights import infer_config, pack_state_dict
-from . import _lib
 
 GN_STATS_MODE = "per_shard_call"      # the default; "global" = pass gn_allreduce(group) as the models' gn_reduce
 
