@@ -311,13 +311,13 @@ int difusco_denoise_step(const difusco_step_args* a) {
       else if (fused) PROF(PROF_EMBED, launch_table_rows_tiled(a->xt, a->perm, ws.table, E, ws.e, st))
       else PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, ws.table, E, H, ws.e, st))
     } else {
-      PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
-      if (fused) {
+      if (fused) {   // sinusoidal features generated inside the linear: the E x H embedding never exists in memory
         const unsigned short* pl = reinterpret_cast<const unsigned short*>(G(DIFUSCO_W_EDGE_EMBED_PLANES)) +
                                    (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0);
-        PROF(PROF_EMBED, linear_rows_split(ws.tmp, pl, (long long)H * H, a->precision, G(DIFUSCO_W_EDGE_EMBED_B), nullptr,
-                                           ws.e, E, H, H, H, st, /*tiled_out=*/1))
+        PROF(PROF_EMBED, linear_scalar_embed_split(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), pl, (long long)H * H,
+                                                   a->precision, G(DIFUSCO_W_EDGE_EMBED_B), ws.e, E, st, /*tiled_out=*/1))
       } else {
+        PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
         PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_PLANES),
                                            G(DIFUSCO_W_EDGE_EMBED_B), nullptr, ws.e))
       }

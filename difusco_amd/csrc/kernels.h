@@ -24,6 +24,11 @@ hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long
                              const float* bias, const float* residual, float* y, long long m, int k, int n_out,
                              long long ldy, hipStream_t stream, int tiled_out = 0);
 
+// Y = ScalarEmbeddingSine(x[perm]) W^T + b, the [m,256] embedding generated inside the kernel (split planes, modes 1 / 3)
+hipError_t linear_scalar_embed_split(const float* x, const int* perm, const float* dimt, const unsigned short* wp,
+                                     long long plane_stride, int mode, const float* bias, float* y, long long m,
+                                     hipStream_t stream, int tiled_out);
+
 hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
                                    const unsigned short* c_planes, const unsigned short* o_planes,
                                    long long plane_stride, const float* b_c, const float* g_e, const float* b_e,

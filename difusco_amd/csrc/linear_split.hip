@@ -62,14 +62,19 @@ struct Fp16 {
   }
 };
 
-template <int K, int FB, int NS, typename T>
+// GEN: the rows of X are not read but generated - ScalarEmbeddingSine of one scalar per row (gnn_encoder.py:230-249):
+// X[r][c] = sin / cos (x[r] / dim_t[c]) for even / odd c, the arithmetic of scalar_embed_kernel.  X then carries the
+// scalars (gen_x, indexed through gen_perm) and the E x H embedding never exists in memory.
+template <int K, int FB, int NS, typename T, bool GEN = false>
 __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* __restrict__ X,
                                                                     const unsigned short* __restrict__ Wp,
                                                                     long long plane_stride,  // elements between planes
                                                                     int n_out_total,
                                                                     const float* __restrict__ bias,
                                                                     const float* residual, float* Y, long long M,
-                                                                    long long ldy, int tiled_out) {
+                                                                    long long ldy, int tiled_out,
+                                                                    const int* __restrict__ gen_perm = nullptr,
+                                                                    const float* __restrict__ gen_dimt = nullptr) {
   constexpr int RB = 128, NB = FB / 32, BK = 16;
   constexpr int RS = 24;                 // LDS row stride in bf16 elements (32 B data + 16 B pad = 48 B)
   constexpr int WV = (FB * 2 + 255) / 256;  // 16-byte chunks per thread per weight plane per slab
@@ -100,7 +105,16 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
       const int row = idx >> 2, c4 = idx & 3;                                                         \
       long long gr = r0 + row;                                                                        \
       gr = gr < M ? gr : M - 1;                                                                       \
-      xr[i] = *reinterpret_cast<const v4f*>(X + gr * K + (KT) + c4 * 4);                              \
+      if constexpr (GEN) {                                                                            \
+        const float xv = X[gen_perm ? gen_perm[gr] : gr];                                             \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
+          const int c = (KT) + c4 * 4 + q;                                                            \
+          const float v = xv / gen_dimt[c];                                                           \
+          xr[i][q] = (c & 1) ? cosf(v) : sinf(v);                                                     \
+        }                                                                                             \
+      } else {                                                                                        \
+        xr[i] = *reinterpret_cast<const v4f*>(X + gr * K + (KT) + c4 * 4);                            \
+      }                                                                                               \
     }                                                                                                 \
     const unsigned short* wslab = Wp + ((long long)((KT) / BK) * n_out_total + f0) * BK;              \
     _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                  \
@@ -187,21 +201,21 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
   }
 }
 
-template <int K, int FB, int NS, typename T>
+template <int K, int FB, int NS, typename T, bool GEN = false>
 static hipError_t launch_split(const float* x, const unsigned short* wp, long long plane_stride, const float* bias,
                                const float* residual, float* y, long long m, int n_out, long long ldy, hipStream_t stream,
-                               int tiled_out) {
+                               int tiled_out, const int* gen_perm = nullptr, const float* gen_dimt = nullptr) {
   constexpr size_t lds = (size_t)NS * (128 + FB) * 24 * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_split_kernel<K, FB, NS, T>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_split_kernel<K, FB, NS, T, GEN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   dim3 grid((unsigned)((m + 127) / 128), (unsigned)(n_out / FB));
-  hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS, T>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
-                     bias, residual, y, m, ldy, tiled_out);
+  hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS, T, GEN>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
+                     bias, residual, y, m, ldy, tiled_out, gen_perm, gen_dimt);
   return hipGetLastError();
 }
 
@@ -229,6 +243,18 @@ hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long
   DIFUSCO_SPLIT_CASE(128, 128)
   DIFUSCO_SPLIT_CASE(64, 64)
 #undef DIFUSCO_SPLIT_CASE
+  return hipErrorInvalidValue;
+}
+
+// Y = ScalarEmbeddingSine(x) W^T + b with the embedding generated inside the kernel (k = n_out = 256 only; modes 1 and 3).
+hipError_t linear_scalar_embed_split(const float* x, const int* perm, const float* dimt, const unsigned short* wp,
+                                     long long plane_stride, int mode, const float* bias, float* y, long long m,
+                                     hipStream_t stream, int tiled_out) {
+  if (m <= 0) return hipSuccess;
+  if (mode == 1)
+    return launch_split<256, 256, 2, Bf16, true>(x, wp, plane_stride, bias, nullptr, y, m, 256, 256, stream, tiled_out, perm, dimt);
+  if (mode == 3)
+    return launch_split<256, 256, 2, Fp16, true>(x, wp, plane_stride, bias, nullptr, y, m, 256, 256, stream, tiled_out, perm, dimt);
   return hipErrorInvalidValue;
 }
 
