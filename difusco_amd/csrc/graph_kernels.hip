@@ -510,8 +510,14 @@ __global__ __launch_bounds__(256) void head_apply_tiled_kernel(const float* __re
                                                                const int* __restrict__ perm, const float* __restrict__ xt,
                                                                PostParams pp, float* __restrict__ xt_out,
                                                                float* __restrict__ pred_out, float* __restrict__ prob_out) {
+  // statistics and the per-channel parameters sit in LDS: every tile re-reads them, 4 channels per lane and chunk
   __shared__ float st[64];
+  __shared__ __attribute__((aligned(16))) float s_gw[256], s_gb[256], s_cw[C][256];
   if (threadIdx.x < 64) st[threadIdx.x] = stats[threadIdx.x];
+  s_gw[threadIdx.x] = gn_w[threadIdx.x];
+  s_gb[threadIdx.x] = gn_b[threadIdx.x];
+#pragma unroll
+  for (int c = 0; c < C; ++c) s_cw[c][threadIdx.x] = conv_w[c * 256 + threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
   const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -521,18 +527,21 @@ __global__ __launch_bounds__(256) void head_apply_tiled_kernel(const float* __re
     float dot[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) dot[c] = 0.0f;
-#pragma unroll 4
+#pragma unroll 8
     for (int ch = 0; ch < 32; ++ch) {                 // chunk ch = 2 ks + i = GroupNorm group
       const v4f x = *reinterpret_cast<const v4f*>(tp + ch * 256);
       const int f = 8 * ch + 4 * hh;
       const float mean = st[2 * ch], rstd = st[2 * ch + 1];
-      const v4f gw = *reinterpret_cast<const v4f*>(gn_w + f), gb = *reinterpret_cast<const v4f*>(gn_b + f);
+      const v4f gw = *reinterpret_cast<const v4f*>(s_gw + f), gb = *reinterpret_cast<const v4f*>(s_gb + f);
+      v4f cw[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) cw[c] = *reinterpret_cast<const v4f*>(&s_cw[c][f]);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         float y = (x[v] - mean) * rstd * gw[v] + gb[v];
         y = y > 0.0f ? y : 0.0f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) dot[c] += y * conv_w[c * 256 + f + v];
+        for (int c = 0; c < C; ++c) dot[c] += y * cw[c][v];
       }
     }
 #pragma unroll
