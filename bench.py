@@ -267,11 +267,18 @@ def main():
             # one E-row linear [E,H] x [H,H]^T.  Algorithmic bytes: read X + write Y (+ read residual for the
             # per_layer_out linear = every second launch) -> 2.5 passes of E*H*4 on average.
             fused = (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3")
-            flops = (4.0 if fused else 2.0) * E_local * H * H     # fused: both E-row GEMMs of the layer in one launch
+            # fused: both E-row GEMMs of a layer in one launch.  The first layer of a table-input step (categorical TSP,
+            # MIS) has no GEMM 1 and reads no e; the last layer of a MIS step has no GEMM 2 and writes no e: the
+            # per-launch averages below account for that (12 launches per step).
+            first_light = fused and not args.no_l0_fold and (mis or not gaussian)
+            last_light = fused and not args.no_gn_fold and mis and LAYERS >= 2
+            gemms = (2.0 * LAYERS - first_light - last_light) / LAYERS if fused else 1.0
+            passes = (2.0 * LAYERS - first_light - last_light) / LAYERS if fused else 2.5
+            flops = 2.0 * gemms * E_local * H * H
             n_prod = {"fp32": 1, "bf16x3": 3, "bf16x6": 6, "fp16x3": 3}[args.precision]
             mfma_peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
             mfma_tf = flops * n_prod / avg_s / 1e12          # matrix-core work actually issued
-            bytes_alg = (2.0 if fused else 2.5) * E_local * H * 4   # fused: e read once + written once per layer
+            bytes_alg = passes * E_local * H * 4   # fused: e read once + written once per layer (see above)
             hbm_gbs = bytes_alg / avg_s / 1e9
             kname = (f"edge_layer_fused_kernel<{'FFp16' if args.precision == 'fp16x3' else 'FBf16'}> (whole edge pass of a "
                      f"layer: 2 chained E-row GEMMs, 3 MFMA products each, gate, 2 LayerNorms, neighbour-sum pieces)"
