@@ -7,6 +7,8 @@ The library is built IN-TREE (difusco_amd/lib/) so that it travels with a snapsh
 import os
 import subprocess
 import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
@@ -33,13 +35,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    # one hipcc per source, in parallel (the fused edge-layer files hold many template instantiations), then one link;
+    # objects live in a temporary directory: only the .so stays in the tree
+    with tempfile.TemporaryDirectory(prefix="difusco_build_") as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+            cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n" + res.stdout + res.stderr)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
+            objs = list(pool.map(compile_one, SOURCES))
+        cmd = [hipcc] + flags + ["-shared", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     return LIB_PATH
 
 
