@@ -36,35 +36,57 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def pmc_traffic_bytes(kernel_name):
+def pmc_traffic_bytes(kernel_name, workload, n_edges, variant):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the
-    gfx950 half-count correction + WRITE_SIZE), as condensed by scripts/summarize_prof.py into
-    profiles/<round>/pmc_traffic.json for the same bench command.  None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    gfx950 half-count correction + WRITE_SIZE; scripts/gpu_profile.sh + scripts/summarize_prof.py).  The table
+    profiles/r02/pmc_traffic.json is keyed by "<workload>:<edges on rank 0>:<variant>", i.e. by the exact run the
+    counters were collected on; a run with no profile of its own reports None (never another workload's bytes)."""
+    path = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
     try:
         table = json.load(open(path))
     except (OSError, ValueError):
         return None
-    for key, val in table.items():
+    entry = table.get(f"{workload}:{n_edges}:{variant}")
+    if not entry:
+        return None
+    for key, val in entry.items():
         if key in kernel_name:
             return {"bytes_per_launch": val["fetch_bytes"] + val["write_bytes"], "fetch_bytes": val["fetch_bytes"],
-                    "write_bytes": val["write_bytes"], "source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc)"}
+                    "write_bytes": val["write_bytes"],
+                    "source": f"profiles/r02/pmc_traffic.json[{workload}:{n_edges}:{variant}] (rocprofv3 --pmc)"}
     return None
 
 
-def cpu_baseline(wl, steps, params):
+def physical_cores():
+    try:
+        import psutil
+        return int(psutil.cpu_count(logical=False) or os.cpu_count() or 1)
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline(wl, steps, params, gpu_model, device):
     """The CPU oracle (port of the reference op sequence, incl. V applied on E gathered rows) on a bounded
-    sample: ONE graph of the same workload, 1 warm-up + `steps` timed denoise steps.  This leg is the only
-    place where bench.py touches oracle/."""
+    sample: ONE graph of the same workload, 1 warm-up + `steps` timed denoise steps, torch threads = physical cores
+    (the default, one thread per SMT sibling, oversubscribes the GEMMs).  The first timed step is also run on the GPU
+    (same graph, same x_t, same injected uniforms, default engine) and the network outputs are compared:
+    "parity_linf".  This leg is the only place where bench.py touches oracle/."""
     from oracle import difusco_oracle as O
     from difusco_amd.synthetic import er_mis_edge_index, tsp_instance
+    cores = physical_cores()
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
+    t_chk, tt_chk = O.inference_schedule("cosine", 1000, 50, 1)
     if wl["task"] == "mis":
         n = 750
         ei = torch.from_numpy(er_mis_edge_index(n, 0.15, seed=1000))
         tab = O.CategoricalTables()
         xt = (torch.randn(n, generator=g) > 0).float()
-        step = lambda xt, t1, t2: O.mis_categorical_denoise_step(params, tab, xt, t1, ei, t2, generator=g)
+        u = torch.rand(n, generator=g)
+        step = lambda xt, t1, t2, **kw: O.mis_categorical_denoise_step(params, tab, xt, t1, ei, t2, **kw)
+        gpu = lambda x: gpu_model.categorical_denoise_step(x.to(device), np.array([t_chk]), device, ei.to(device),
+                                                           target_t=np.array([tt_chk]), uniform=u, return_aux=True)
         what = f"1 graph ER-{n} p=0.15 ({ei.shape[1]} directed edges incl. self loops)"
     else:
         pts, ei = tsp_instance(wl["nodes"], wl["knn"], seed=1000)
@@ -73,21 +95,50 @@ def cpu_baseline(wl, steps, params):
         if wl["diffusion"] == "gaussian":
             tab = O.GaussianTables()
             xt = torch.randn(ei.shape[1], generator=g)
-            step = lambda xt, t1, t2: O.tsp_gaussian_denoise_step(params, tab, pts, xt, t1, ei, t2)
+            u = None
+            step = lambda xt, t1, t2, **kw: O.tsp_gaussian_denoise_step(params, tab, pts, xt, t1, ei, t2,
+                                                                        **{k: v for k, v in kw.items() if k == "return_aux"})
+            gpu = lambda x: gpu_model.gaussian_denoise_step(pts.to(device), x.to(device), np.array([t_chk]), device,
+                                                            ei.to(device), target_t=np.array([tt_chk]), return_aux=True)
         else:
             tab = O.CategoricalTables()
             xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
-            step = lambda xt, t1, t2: O.tsp_categorical_denoise_step(params, tab, pts, xt, t1, ei, t2, generator=g)
+            u = torch.rand(ei.shape[1], generator=g)
+            step = lambda xt, t1, t2, **kw: O.tsp_categorical_denoise_step(params, tab, pts, xt, t1, ei, t2, **kw)
+            gpu = lambda x: gpu_model.categorical_denoise_step(pts.to(device), x.to(device), np.array([t_chk]), device,
+                                                               ei.to(device), target_t=np.array([tt_chk]), uniform=u,
+                                                               return_aux=True)
+    parity = {}
     with torch.no_grad():
-        xt = step(xt, 1000, 969)
+        xt = step(xt, 1000, 969, **({} if u is None else {"generator": g}))       # warm-up
         t0 = time.perf_counter()
         for i in range(steps):
             t1, t2 = O.inference_schedule("cosine", 1000, 50, i + 1)
-            xt = step(xt, t1, t2)
+            if i == 0:          # the checked step: teacher-forced on both sides
+                res = step(xt, t1, t2, return_aux=True, **({} if u is None else {"uniform": u}))
+                got = gpu(xt)
+                torch.cuda.synchronize(device)
+                parity["parity_linf"] = float((got[1].cpu().reshape(res[1].shape) - res[1]).abs().max())
+                if u is not None:
+                    pr = res[2].reshape(-1)
+                    parity["parity_prob_linf"] = float((got[2].cpu().reshape(-1) - pr).abs().max())
+                    safe = (u - pr).abs() > 1e-4
+                    parity["parity_bits_equal"] = bool(torch.equal(got[0].cpu()[safe], res[0][safe]))
+                else:
+                    parity["parity_xt_linf"] = float((got[0].cpu() - res[0]).abs().max())
+                parity["parity_what"] = (f"network output of step (t={t1} -> {t2}) of that graph, HIP path (default engine) vs "
+                                         f"CPU oracle, same x_t and uniforms; tolerance 1e-4")
+                xt = res[0]
+            else:
+                xt = step(xt, t1, t2, **({} if u is None else {"generator": g}))
         dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "graph-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{what} H={H} L={LAYERS} fp32 {wl['diffusion']}, 1 warm-up + {steps} timed steps "
-                      f"of the CPU oracle ({dt:.1f} s)"}
+    torch.set_num_threads(prev_threads)
+    out = {"value": steps / dt, "unit": "graph-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{what} H={H} L={LAYERS} fp32 {wl['diffusion']}, 1 warm-up + {steps} timed steps "
+                     f"of the CPU oracle ({dt:.1f} s, incl. one GPU step for the parity check), "
+                     f"torch.set_num_threads({cores}) = physical cores"}
+    out.update(parity)
+    return out
 
 
 # BASELINE.json configs[1..4].  tsp1000 is the configuration the metric is quoted on (the default; it fits one GPU
@@ -124,6 +175,10 @@ def main():
     ap.add_argument("--gn-stats", default="per_shard_call", choices=["per_shard_call", "global"],
                     help="head GroupNorm statistics: over each rank's own call (default, no collective in the loop) or "
                          "over the whole sharded batch (one all-reduce of 65 doubles per step)")
+    ap.add_argument("--fused-opt", type=int, default=None, help="A/B: scheduling options of the fused kernel "
+                    "(difusco_debug_set key 7; bit 0 XCD-contiguous tile ranges, bit 1 alternating MFMA chains)")
+    ap.add_argument("--no-node-reorder", action="store_true", help="A/B: keep the caller's node numbering (no Morton order)")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32 (v_mfma_f32_32x32x2_f32) sub-record")
     ap.add_argument("--precision", default="fp16x3", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
                     help="arithmetic of the E-row linears: exact fp32 MFMA, or fp32 split into 2/3 bf16 planes "
                          "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
@@ -162,6 +217,8 @@ def main():
         _lib.check(_lib.lib().difusco_debug_set(3, 0))
     if args.no_gn_fold:
         _lib.check(_lib.lib().difusco_debug_set(4, 0))
+    if args.fused_opt is not None:
+        _lib.check(_lib.lib().difusco_debug_set(7, args.fused_opt))
     from difusco_amd.dist import engine_from_broadcast, gn_allreduce, shard_range
     from difusco_amd.engine import DenoiseEngine
     from difusco_amd.models import MISModel, TSPModel
@@ -178,7 +235,8 @@ def main():
                  inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn if not mis else -1,
                  n_layers=LAYERS, hidden_dim=H, inference_trick="ddim")
     gn_reduce = gn_allreduce() if (args.gn_stats == "global" and world > 1) else None
-    model = (MISModel if mis else TSPModel)(margs, engine=engine, seed=1234 + rank, gn_reduce=gn_reduce)
+    model = (MISModel if mis else TSPModel)(margs, engine=engine, seed=1234 + rank, gn_reduce=gn_reduce,
+                                            reorder_nodes=not args.no_node_reorder)
 
     # this rank's shard of the global batch (weak scaling: graphs_per_gpu fixed)
     G_total = args.graphs_per_gpu * world
@@ -203,14 +261,15 @@ def main():
     E_local = edge_index.shape[1]
     sched = InferenceSchedule("cosine", T=1000, inference_T=50)
 
-    def one_step(i, xt):
+    def one_step(i, xt, mdl=None):
+        mdl = model if mdl is None else mdl
         t1, t2 = sched(i % 49)                                  # never the final (t2 = 0) step: keeps xt binary
         t1, t2 = np.array([t1]), np.array([t2])
         if mis:
-            return model.categorical_denoise_step(xt, t1, device, edge_index, target_t=t2)
+            return mdl.categorical_denoise_step(xt, t1, device, edge_index, target_t=t2)
         if gaussian:
-            return model.gaussian_denoise_step(points, xt, t1, device, edge_index, target_t=t2)
-        return model.categorical_denoise_step(points, xt, t1, device, edge_index, target_t=t2)
+            return mdl.gaussian_denoise_step(points, xt, t1, device, edge_index, target_t=t2)
+        return mdl.categorical_denoise_step(points, xt, t1, device, edge_index, target_t=t2)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -259,7 +318,9 @@ def main():
                        "nodes": args.nodes, "knn": args.knn, "nodes_rank0": N_local, "edges_rank0": E_local,
                        "gn_stats": args.gn_stats,
                        "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision,
-                       "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3")},
+                       "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3"),
+                       "node_order": "caller" if (args.no_node_reorder or mis) else "morton per graph (graph.py)",
+                       "fused_opt": args.fused_opt},
         }
         if prof is not None and prof["launches"][0] > 0:
             n_lin = prof["launches"][0]
@@ -293,12 +354,20 @@ def main():
             else:
                 out["roofline"] = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": None}
-            out["roofline"]["traffic"] = pmc_traffic_bytes(kname)
+            variant = ("fused" if fused else "unfused") + "-" + args.precision
+            out["roofline"]["traffic"] = pmc_traffic_bytes(kname, args.workload, E_local, variant)
+            # "achieved" / "frac" count the matrix work ISSUED (every fp32 product is carried by n_prod 16-bit MFMA
+            # products); frac_algorithmic counts each algorithmic flop once against the same peak, and
+            # frac_fp32_mfma_peak against the exact-fp32 MFMA peak (what the arithmetic would cost unsplit)
             out["roofline"].update({"kernel": kname, "avg_launch_ms": avg_s * 1e3, "launches": n_lin,
                                     "algorithmic_flops_per_launch": flops, "mfma_products": n_prod,
                                     "algorithmic_bytes_per_launch": bytes_alg,
                                     "mfma_TFLOPs_issued": mfma_tf, "mfma_peak_TFLOPs": mfma_peak,
-                                    "hbm_GBs_algorithmic": hbm_gbs})
+                                    "algorithmic_TFLOPs": flops / avg_s / 1e12,
+                                    "frac_algorithmic": flops / avg_s / 1e12 / mfma_peak,
+                                    "frac_fp32_mfma_peak": flops / avg_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                    "hbm_GBs_algorithmic": hbm_gbs, "hbm_frac_of_8TBs": hbm_gbs / PEAK_HBM_GBS,
+                                    "other_ms_per_step": 1e3 * dt / args.steps - avg_s * 1e3 * n_lin / args.steps})
             n_g = max(prof["launches"][2], 1)
             g_s = prof["ms"][2] / n_g * 1e-3
             if fused:
@@ -326,8 +395,27 @@ def main():
                 "embed_misc": {"ms_total": prof["ms"][4], "launches": prof["launches"][4]},
                 "sum_ms_per_step": sum(prof["ms"]) / args.steps,
             })
+        if world == 1 and not args.no_exact_fp32 and args.precision != "fp32":
+            # the same workload with every E-row contraction on v_mfma_f32_32x32x2_f32 (exact fp32, no split planes):
+            # the number to read when the split-precision arithmetic of the headline is not accepted
+            eng32 = DenoiseEngine(params, device=device, blob=engine.blob, precision="fp32", fused=False)
+            m32 = (MISModel if mis else TSPModel)(margs, engine=eng32, seed=1234, reorder_nodes=not args.no_node_reorder)
+            x32 = one_step(0, xt, m32)
+            fence()
+            n32 = max(2, min(4, args.steps))
+            t0 = time.perf_counter()
+            for i in range(n32):
+                x32 = one_step(1 + i, x32, m32)
+            fence()
+            d32 = time.perf_counter() - t0
+            del eng32, m32, x32
+            out["exact_fp32"] = {"value": G_total * n32 / d32, "unit": "graph-steps/s", "ms_per_step": 1e3 * d32 / n32,
+                                 "steps": n32, "edge_linear_arithmetic": "fp32 (v_mfma_f32_32x32x2_f32), unfused kernel sequence",
+                                 "same_workload": True}
         if world == 1 and args.cpu_steps > 0:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, params)
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, params, model, device)
+            if "parity_linf" in out["cpu_baseline"]:
+                out["parity_linf"] = out["cpu_baseline"]["parity_linf"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

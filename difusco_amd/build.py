@@ -14,8 +14,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdifusco_hip.so")
-SOURCES = ["linear.hip", "linear_split.hip", "edge_layer.hip", "edge_layer_pipe.hip", "graph_kernels.hip", "decode.hip", "two_opt.hip", "knn.hip", "mis_decode.hip", "api.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "edge_layer_common.h"),
+SOURCES = ["linear.hip", "linear_split.hip", "edge_layer.hip", "edge_layer_bf16.hip", "edge_layer_abl.hip", "graph_kernels.hip", "decode.hip", "two_opt.hip", "knn.hip", "mis_decode.hip", "api.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "edge_layer_common.h"), os.path.join(CSRC, "edge_layer_kernel.h"),
            os.path.join(os.path.dirname(PKG), "include", "difusco_hip.h")]
 
 

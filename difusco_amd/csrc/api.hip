@@ -277,10 +277,9 @@ int difusco_denoise_step(const difusco_step_args* a) {
   // kernel takes it from the table and the pass that would write e0 to HBM is skipped
   // last layer (at least two layers).  TSP: the fused kernel also emits the head's GroupNorm partial sums per tile and
   // skips the node update nobody reads; MIS: it skips the edge output nobody reads.
-  const bool tail_fold = fused && L >= 2 && difusco::g_fused_gn_fold != 0 && difusco::g_fused_variant == 0 &&
-                         difusco::g_fused_ablate == 0;
+  const bool tail_fold = fused && L >= 2 && difusco::g_fused_gn_fold != 0 && difusco::g_fused_ablate == 0;
   const bool gn_fold = tail_fold && tsp;
-  const bool l0_fold = fused && difusco::g_fused_l0_fold != 0 && difusco::g_fused_variant == 0 &&
+  const bool l0_fold = fused && difusco::g_fused_l0_fold != 0 &&
                        difusco::g_fused_ablate == 0 && (tsp ? a->xt_is_binary != 0 : true);
 
   // per-layer time bias rows: time_layer_l(time_embed(timestep_embedding(t)))   [L,H]
@@ -502,10 +501,10 @@ int difusco_debug_set_ptr(int key, void* p) {
 
 int difusco_debug_set(int key, int value) {
   if (key == 0) { difusco::g_fused_ablate = value; return DIFUSCO_OK; }
-  if (key == 2) { difusco::g_fused_variant = value; return DIFUSCO_OK; }
   if (key == 3) { difusco::g_fused_l0_fold = value; return DIFUSCO_OK; }
   if (key == 4) { difusco::g_fused_gn_fold = value; return DIFUSCO_OK; }
   if (key == 6) { difusco::g_fused_lds_pad = value; return DIFUSCO_OK; }
+  if (key == 7) { difusco::g_fused_opt = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }
 

@@ -1,0 +1,23 @@
+// Profiling-only variants of the fp16 middle-layer kernel (edge_layer_kernel.h): compile-time ablation masks selected
+// with difusco_debug_set(0, mask).  Results are WRONG for every mask except 16 (production code + phase timestamps).
+#include "edge_layer_kernel.h"
+
+namespace difusco {
+hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS) {
+  (void)l0_table; (void)l0_x; (void)l0_perm; (void)gn_tile;
+#define ABL_ARGS e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, \
+                 time_on_edge, part, direct, stream
+  switch (mask) {
+    case 1: return launch_fused_t<FFp16, 1, FUSED_NW>(ABL_ARGS);      // no neighbour-table gathers
+    case 2: return launch_fused_t<FFp16, 2, FUSED_NW>(ABL_ARGS);      // no neighbour sum
+    case 4: return launch_fused_t<FFp16, 4, FUSED_NW>(ABL_ARGS);      // no LayerNorm / activation math
+    case 8: return launch_fused_t<FFp16, 8, FUSED_NW>(ABL_ARGS);      // no GEMM 2
+    case 15: return launch_fused_t<FFp16, 15, FUSED_NW>(ABL_ARGS);    // GEMM 1 + weight streaming only
+    case 16: return launch_fused_t<FFp16, 16, FUSED_NW>(ABL_ARGS);    // production code + phase timestamps
+    case 17: return launch_fused_t<FFp16, 15, FUSED_NW, false, false, 0, 2>(ABL_ARGS);   // 15 with alternating MFMA chains
+    case 18: return launch_fused_t<FFp16, 16, FUSED_NW, false, false, 0, 3>(ABL_ARGS);   // 16 with OPT 3
+    default: return hipErrorInvalidValue;
+  }
+#undef ABL_ARGS
+}
+}  // namespace difusco

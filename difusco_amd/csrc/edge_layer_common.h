@@ -1,4 +1,4 @@
-// Shared pieces of the fused edge-layer kernels (edge_layer.hip, edge_layer_pipe.hip): 16-bit element traits,
+// Shared pieces of the fused edge-layer kernel (edge_layer.hip): 16-bit element traits,
 // fp32 -> two-plane split, LDS swizzle of the weight stages, fast sigmoid.
 #pragma once
 #include "common.h"

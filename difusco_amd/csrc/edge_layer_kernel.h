@@ -1,0 +1,754 @@
+// Fused edge pass of one DIFUSCO GNN layer for gfx950 (H = 256): the edge state e is read ONCE and
+// written ONCE per layer.
+//
+//   Ce    = C e                                    gnn_encoder.py:104           GEMM 1 (matrix cores)
+//   e'    = Ah[j] + Bh[i] + (Ce + b_C)             :110
+//   m     = sigmoid(e') * Vh[j]  -> sum over the edges of centre node i          :112,:115,:163,:177-191
+//   y     = ReLU(LN_e(e')) (+ t_l, TSP)            :131,:135,:445
+//   a     = SiLU(LN_o(y))                          per_layer_out[l][0:2] :339-342
+//   e    += W_o a + b_o                            per_layer_out[l][2] :344, residual :449   GEMM 2
+//
+// Chained, transposed MFMA.  Both GEMMs are computed as D[f][edge] = sum_k W[f][k] X[edge][k] (A operand =
+// 32 weight rows, B operand = 32 edges), so in the 32x32 accumulator a lane owns, for ITS edge (lane&31),
+// the features {32 nb + 8 g + 4 hh + 0..3} - half of the 256 features, the other half sits in lane+32.
+//   * LayerNorm over the 256 features of an edge = in-lane sum over 128 registers + ONE cross-half exchange.
+//   * Eight consecutive accumulator registers of a block are exactly the B operand (8 k values per lane
+//     half) of a 32x32x16 MFMA: the epilogued accumulators of GEMM 1 feed GEMM 2 straight from registers,
+//     no LDS round trip.  The weight planes are stored in that k order (weights.py: slab position order
+//     {0..3, 8..11, 4..7, 12..15}).
+//   * fp32 operands are split into two 16-bit planes (fp16: 22 significand bits, or bf16) and multiplied
+//     with 3 MFMA products (hi*hi, hi*lo, lo*hi), accumulated in fp32 (see linear_split.hip).
+// A wave owns a 32-edge tile end to end; a workgroup is NW = 4 waves (two workgroups per CU, whose phases drift
+// apart so that one's MFMA phases overlap the other's VALU / address-heavy epilogue) or NW = 8 (one per CU, half
+// the L2 weight traffic, phases in lock step) - see fused::Geo; 4 measured ~10 % faster.
+// Weights stream through LDS in stages of 64 NW rows of 32 bytes x 2 planes ([256 rows][16 k] slabs for GEMM 1,
+// [64 rows][16 k] sub-slabs of one output quarter for GEMM 2), double buffered, filled by LDS-DMA
+// (buffer_load_dwordx4 ... lds, no staging registers), one barrier per stage; the rows are XOR-swizzled so every
+// 16-lane group of ds_read_b128 hits 16 distinct 16-byte bank slots without padding (the swizzle is applied to the
+// per-lane source address of the DMA, whose LDS side is lane-linear).  GEMM 2 runs in four quarters of 64 output features (32
+// accumulator registers) so that act planes (128) + accumulators + staging fit 256 VGPRs (2 waves/SIMD).
+//
+// Neighbour sum.  The gated messages m of a tile are transposed through a wave-private LDS scratch
+// (64 features per round) and summed per centre-node segment by lanes = features.  A segment that is
+// the first or last of its tile may continue in the neighbouring tile: it goes to part[tile][0|1];
+// segments strictly inside a tile are complete and go to direct[node].  node_finalize_kernel adds the
+// pieces of each node in tile order - deterministic, no atomics.
+//
+// First layer (template flag L0): when the edge input is a lookup in a 2-row table (categorical TSP: the embedding
+// of the bit x_t; MIS: zeros) the table sits in LDS and the kernel never reads e - see the L0 notes at the kernel.
+// This header holds the kernel template and its launcher template; the instantiations are spread over
+// edge_layer.hip (fp16 production variants), edge_layer_bf16.hip and edge_layer_abl.hip (profiling-only ablations) so
+// that the translation units compile in parallel.
+#pragma once
+#include "edge_layer_common.h"
+
+namespace difusco {
+
+namespace fused {
+constexpr int H = 256;
+constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregation scratch (64 + 4 pad)
+enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT, P_TAB0, P_TAB1, P_CE0, P_CE1, P_COUNT };
+// P_TAB*: layer-0 input table rows; P_CE*: C (weight of GEMM 1) applied to those rows
+
+// Workgroup geometry (template parameter NW of the kernel is a geometry code).  A workgroup is WAVES tiles of 32
+// edges; a weight stage holds ENT rows of 32 bytes per plane:
+//   code 8 : 8 waves, 512 rows (32 KiB / stage), 16 stages, ONE workgroup per CU: every weight byte fetched from L2
+//            serves 256 edges, but all 8 waves walk the phases (GEMM 1, epilogue, GEMM 2) in lock step;
+//   code 4 : 4 waves, 256 rows (16 KiB / stage), 32 stages, TWO workgroups per CU that drift apart, so one
+//            workgroup's MFMA phases overlap the other's VALU / address-unit heavy epilogue;
+//   code 40: 4 waves, 512 rows (32 KiB / stage), 16 stages, two workgroups per CU: half the barriers of code 4.
+//            The 2 x 32 KiB of stage buffers only fit beside the aggregation scratch because the scratch ALIASES
+//            stage buffer 1 (+ 2 KiB): the scratch is used between the GEMMs only, the last GEMM 1 stage is the last
+//            reader of buffer 1 (barrier), and the first refill of buffer 1 in GEMM 2 waits for a barrier after the
+//            epilogue.  Measured: barriers + stage refills cost 0.09 ms per GEMM phase with 16 KiB stages.
+template <int CODE>
+struct Geo {
+  static constexpr bool ALIAS = CODE == 40;
+  static constexpr int WAVES = CODE == 8 ? 8 : 4;
+  static constexpr int THREADS = 64 * WAVES;
+  static constexpr int ENT = CODE == 4 ? 256 : 512;   // entries (32-byte rows) per plane per stage
+  static constexpr int PP = ENT / 32 / WAVES;      // 1 KiB LDS-DMA pieces per wave, plane and stage (2 | 2 | 4)
+  static constexpr int PLANE = ENT * 16;        // 16-bit elements per plane per stage
+  static constexpr int BUF = 2 * PLANE;         // one stage buffer: 2 planes
+  static constexpr int SPS = ENT / 256;         // GEMM 1: slabs per stage
+  static constexpr int NS1 = 16 / SPS;          // GEMM 1 stages
+  static constexpr int KPS = ENT / 64;          // GEMM 2: k slabs per stage
+  static constexpr int SPQ = 16 / KPS;          // GEMM 2: stages per output quarter
+  static constexpr int NSTAGE = NS1 + 4 * SPQ;  // 16 | 32 | 16
+  static constexpr int LDS_W = 2 * BUF * 2;     // bytes, double buffered             65536 | 32768 | 65536
+  static constexpr int LDS_P = P_COUNT * H * 4; // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O, table rows (4) 11264
+  static constexpr int LDS_S = WAVES * 32 * SCR_STRIDE * 4;   // bytes                69632 | 34816 | 34816
+  // ALIAS: [buffer 0][buffer 1 = scratch ...][... scratch tail][parameters]; else [buffers][parameters][scratch]
+  static constexpr int OFF_S = ALIAS ? BUF * 2 : LDS_W + LDS_P;
+  static constexpr int OFF_P = ALIAS ? BUF * 2 + LDS_S : LDS_W;
+  static constexpr int LDS_TOTAL = ALIAS ? BUF * 2 + LDS_S + LDS_P : LDS_W + LDS_P + LDS_S;   // 146432 | 78848 | 78848
+  static_assert(!ALIAS || LDS_S >= BUF * 2, "the aliased scratch must cover stage buffer 1");
+};
+constexpr int geo_waves(int code) { return code == 8 ? 8 : 4; }
+}  // namespace fused
+
+template <typename T, int ABL, int NW, bool L0, bool GNP, int TAIL, int OPT>
+__global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused_kernel(
+    float* e, const float* __restrict__ node4, const int* __restrict__ row, const int* __restrict__ col, int n_edges,
+    const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
+    const float* __restrict__ b_c, const float* __restrict__ g_e, const float* __restrict__ b_e,
+    const float* __restrict__ tbias, const float* __restrict__ g_o, const float* __restrict__ b_o,
+    const float* __restrict__ b_out, int time_on_edge, float* __restrict__ part, float* __restrict__ direct,
+    unsigned long long* dbg,     // dbg: optional phase timestamps (profiling), nullptr in production
+    const float* __restrict__ l0_table, const float* __restrict__ l0_x, const int* __restrict__ l0_perm,
+    float* __restrict__ gn_tile) {
+  // TAIL: what the step still needs from this layer.  0 = everything.  1 = last layer of a TSP step: the head reads
+  // only e, so the node update is dead work - no V h gathers, no gate, no neighbour sum (the caller skips
+  // node_finalize).  2 = last layer of a MIS step: the head reads only h, so the edge output is dead work - the kernel
+  // ends after the neighbour sum (no LayerNorms, no GEMM 2, no store of e).  The reference computes both and discards
+  // them (gnn_encoder.py:400-401 / :412-413 read one of the two states).
+  // GNP (last layer of a step whose head reads e): per tile and GroupNorm group (8 channels = the two lane halves of
+  // one (quarter, block, quad)), the sum and the sum of squares of the NEW e values go to gn_tile[tile][32][2]; the
+  // head then needs no statistics pass over e (nn.py:93-100, gnn_encoder.py:400-401).
+  // L0 (first layer of a step whose edge input is a table lookup): e_in[s] = l0_table[x > 0.5 ? 1 : 0] with
+  // x = l0_x[l0_perm ? l0_perm[s] : s] (categorical TSP: the edge embedding of the bit x_t, gnn_encoder.py:395) or
+  // row 0 when l0_x is null (MIS: e = zeros, gnn_encoder.py:407).  The kernel then never reads e, and it has no GEMM 1
+  // either: with only two distinct input rows, C e_in is one of two vectors (l0_table rows 2, 3 = C applied to rows 0,
+  // 1, computed once per step by an exact fp32 linear on two rows); the accumulators start from that row, the
+  // residual comes from the input row, and the separate embedding pass over e disappears.
+  // OPT: scheduling options that do not change any result bit (A/B through difusco_debug_set(7, ..)):
+  //   bit 0  XCD-contiguous tile ranges: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only); the
+  //          remap gives every XCD one contiguous range of tiles, so that - with the nodes of a graph in Morton order
+  //          (graph.py) - the neighbour-table rows A h[j], V h[j] gathered by one XCD's workgroups are a small, spatially
+  //          compact set that stays in that XCD's 4 MiB L2;
+  //   bit 1  the MFMAs of two weight blocks are issued alternately (two independent accumulator chains), so that no
+  //          MFMA waits for the result of the one issued right before it.
+  // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
+  // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
+  constexpr int ablate = ABL;
+  using namespace fused;
+  typedef Geo<NW> G_;
+  constexpr int WAVES = G_::WAVES, PLANE = G_::PLANE, BUF = G_::BUF, NSTAGE = G_::NSTAGE, SPS = G_::SPS, NS1 = G_::NS1,
+                KPS = G_::KPS, SPQ = G_::SPQ, PP = G_::PP;
+  typedef typename T::frag frag;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* wbuf = reinterpret_cast<unsigned short*>(smem_raw);
+  float* prm = reinterpret_cast<float*>(smem_raw + G_::OFF_P);
+  float* scr_all = reinterpret_cast<float*>(smem_raw + G_::OFF_S);
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  if constexpr ((OPT & 1) != 0) {      // bijective for any grid size (cdna_hip_programming.md T1)
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  const int tile = bid * WAVES + wave;
+  const int s_raw = tile * 32 + l31;
+  const bool valid = s_raw < n_edges;
+  const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
+  // e is stored TILED ("MFMA native", see edge_tiled_offset in kernels.h): per 32-edge tile the 1 KiB that one
+  // wave instruction touches is contiguous, so every access below is a fully coalesced 1 KiB transaction
+  // Addressing is (wave-uniform 64-bit base + compile-time constant) + 32-bit lane offset so that the loads use
+  // the scalar-base form; per-lane 64-bit pointers with large constant offsets cost a VGPR pair per address.
+  float* const etile = e + (long long)tile * (32 * H);   // + slab * 512 + i * 256 + loff
+  const unsigned loff = lane * 4;
+  float* scr = scr_all + wave * 32 * SCR_STRIDE;
+  // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
+  unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define FUSED_STAMP(k) \
+  if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();
+  FUSED_STAMP(0)
+
+  // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}] = two float4 of the tiled
+  // layout = 2 KiB per wave and slab, cold HBM reads.
+  // A register ring, RING slabs ahead of the MFMAs.  (Routing this stream through LDS-DMA into the idle aggregation
+  // scratch was measured 2.5 % slower - profiles/r01/fused_kernel_study.txt - and removed.)
+  constexpr bool kDma = (ABL & 2048) == 0;                          // weight stages by LDS-DMA (else registers)
+  // profiling only (wrong results): matrix phases without stage refills and barriers / without the e stream
+  constexpr bool kNoSync = (ABL & 16384) != 0, kNoE = (ABL & 32768) != 0;
+  static_assert(kDma || !G_::ALIAS, "geometry 40 has no register-staged variant");
+  constexpr int RING = kDma ? 2 : 4;   // beside LDS-DMA staging every load is drained at the stage barrier
+  v4f er[RING][2];
+  if constexpr (L0) {
+    // no e stream
+  } else {
+#pragma unroll
+    for (int d = 0; d < RING; ++d) {
+      er[d][0] = *reinterpret_cast<const v4f*>(etile + d * 512 + loff);
+      er[d][1] = *reinterpret_cast<const v4f*>(etile + (d * 512 + 256) + loff);
+    }
+  }
+
+  // ---- weight stage streaming ---------------------------------------------------------------------
+  // A stage is 512 rows of 32 bytes per plane (32 KiB for the two planes):
+  //   stage t < 8 : GEMM 1, slabs 2t, 2t+1 of C;  entry = sub * 256 + weight row  (sub = slab - 2t)
+  //   stage 8 + u : GEMM 2, output quarter qt = u >> 1 (64 features), slabs 8 kc .. 8 kc + 7 of W_o (kc = u & 1);
+  //                 entry = ksl * 64 + (row - 64 qt)
+  // Two 16-byte chunks per thread per plane.  Stage t lives in LDS buffer t & 1; its global loads are issued
+  // at the top of iteration t - 1 and parked in LDS at its end: 48 MFMAs per wave cover the L2 latency, and
+  // there is one barrier per 48 MFMAs.
+  // source of chunk c (entry = c >> 1, half = c & 1) of stage t = uniform stage base + a per-thread offset that does
+  // not depend on t (one for the GEMM 1 stage shape, one for the GEMM 2 shape)
+  unsigned voff1[2], voff2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + G_::THREADS * i, entry = c >> 1, half = c & 1;
+    voff1[i] = (entry >> 8) * 4096 + (entry & 255) * 16 + half * 8;
+    voff2[i] = (entry >> 6) * 4096 + (entry & 63) * 16 + half * 8;
+  }
+  auto stage_base = [&](int t) -> const unsigned short* {      // wave uniform
+    if (t < NS1) return c_planes + (long long)(SPS * t) * 4096;
+    const int u = t - NS1, qt = u / SPQ, kc = u % SPQ;
+    return o_planes + (long long)(KPS * kc) * 4096 + 64 * qt * 16;
+  };
+  v4u wr[2][2];   // [plane][chunk]
+#define FUSED_LOAD_STAGE(t)                                                        \
+  {                                                                                \
+    const unsigned short* sb = stage_base(t);                                      \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
+      const unsigned vo = (t) < NS1 ? voff1[i] : voff2[i];                         \
+      wr[0][i] = *reinterpret_cast<const v4u*>(sb + vo);                           \
+      wr[1][i] = *reinterpret_cast<const v4u*>(sb + plane_stride + vo);            \
+    }                                                                              \
+  }
+#define FUSED_STORE_STAGE(t)                                                       \
+  {                                                                                \
+    unsigned short* dst = wbuf + ((t) & 1) * BUF;                                  \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
+      const int c = tid + G_::THREADS * i;                                         \
+      const int off = wslot(c >> 1, c & 1);                                        \
+      *reinterpret_cast<v4u*>(dst + off) = wr[0][i];                               \
+      *reinterpret_cast<v4u*>(dst + PLANE + off) = wr[1][i];                       \
+    }                                                                              \
+  }
+  // Write-early pipeline.  Iteration t: park stage t+1 in LDS (its loads were issued one whole iteration ago),
+  // issue the loads of stage t+2 (pinned at the top by the sched_barrier: the register-pressure-driven scheduler
+  // otherwise sinks them next to their use and exposes the L2 latency once per stage), multiply stage t, barrier.
+  // The first GEMM 2 stage pair straddles the epilogue: stage NS1+1 is fetched after it, not held across it.
+  // LDS-DMA staging (production; ABL & 2048 selects the older register-staged path for A/B): global_load_lds_dwordx4
+  // moves 1 KiB per wave instruction from global memory
+  // straight into the stage buffer - no staging registers, no ds_write.  The LDS image is the same swizzled image
+  // the register path builds: lane L of wave w, instruction i (0, 1) fills slot (2 w + i) * 64 + L of a plane, i.e.
+  // entry = (2 w + i) * 32 + (L >> 1), and fetches the half that belongs there (the XOR of wslot applied on the
+  // source side; both halves of an entry are adjacent in global memory, so coalescing is unchanged).
+  // Protocol: iteration t requests stage t+1 into the other buffer (everybody left it at the last barrier),
+  // multiplies stage t, then waits for its own requests (vmcnt(0)) before the barrier.
+  unsigned dvoff1 = 0, dvoff2 = 0;
+  if constexpr (kDma) {
+    const int entry0 = (PP * wave) * 32 + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
+    dvoff1 = (entry0 >> 8) * 4096 + (entry0 & 255) * 16 + half * 8;
+    dvoff2 = (entry0 >> 6) * 4096 + (entry0 & 63) * 16 + half * 8;
+  }
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c_planes), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(o_planes), 0, 0x7fffffff, 0x00020000);
+  const int plane_bytes = (int)plane_stride * 2;
+  // piece i of this wave (i < PP): LDS slot block PP*wave + i; its source lies i * 512 elements further in a GEMM 1
+  // stage ([slab][256 rows][16]) and (i >> 1) * 4096 + (i & 1) * 512 in a GEMM 2 stage ([k slab][64 rows][16]) when a
+  // wave covers more than one k slab (PP = 4), i * 512 otherwise
+#define FUSED_DMA_STAGE(t)                                                                                   \
+  {                                                                                                          \
+    const int u_ = (t) - NS1;                                                                                \
+    const int sbase = (t) < NS1 ? SPS * (t) * 4096 * 2 : ((KPS * (u_ % SPQ)) * 4096 + 64 * (u_ / SPQ) * 16) * 2; \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                         \
+      _Pragma("unroll") for (int i = 0; i < PP; ++i) {                                                       \
+        const int src_off = ((t) < NS1 || PP == 2) ? i * 512 : (i >> 1) * 4096 + (i & 1) * 512;             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                            \
+            (t) < NS1 ? rs_c : rs_o,                                                                         \
+            (__attribute__((address_space(3))) void*)(wbuf + ((t) & 1) * BUF + pl * PLANE + (PP * wave + i) * 512), 16, \
+            ((t) < NS1 ? dvoff1 : dvoff2) * 2, sbase + pl * plane_bytes + src_off * 2, 0, 0);                \
+      }                                                                                                      \
+  }
+#define FUSED_PIPE_BEGIN(t)                                         \
+  if constexpr (kNoSync) {                                          \
+  } else if constexpr (kDma) {                                      \
+    if (G_::ALIAS && (t) == NS1) __syncthreads();   /* every wave has left the scratch = stage buffer 1 */ \
+    if ((t) + 1 < NSTAGE) {                                         \
+      FUSED_DMA_STAGE((t) + 1)                                      \
+      __builtin_amdgcn_sched_barrier(0);                            \
+    }                                                               \
+  } else {                                                          \
+    if ((t) + 1 < NSTAGE) FUSED_STORE_STAGE((t) + 1)                \
+    if ((t) + 2 < NSTAGE && (t) + 2 != NS1 + 1) {                   \
+      FUSED_LOAD_STAGE((t) + 2)                                     \
+      __builtin_amdgcn_sched_barrier(0);                            \
+    }                                                               \
+  }
+  // end of iteration t: the requests of stage t+1 must have landed before the barrier.  In GEMM 1 with the e
+  // stream on the DMA queue as well, the two youngest requests are slab t+2 of e, which may stay in flight.
+#define FUSED_PIPE_END(t)                                                        \
+  if (!kNoSync && (t) + 1 < NSTAGE) {                                            \
+    if constexpr (kDma) {                                                        \
+      __builtin_amdgcn_s_waitcnt(0x0F70);                            /* vmcnt(0) */ \
+    }                                                                            \
+    __syncthreads();                                                             \
+  }
+
+  static_assert(!L0 || kDma, "the first-layer variant exists for the LDS-DMA staging only");
+  if constexpr (L0) { FUSED_DMA_STAGE(NS1) }           // no GEMM 1: the stage stream starts with GEMM 2
+  else if constexpr (kDma) { FUSED_DMA_STAGE(0) } else { FUSED_LOAD_STAGE(0) }
+
+  // layer parameters -> LDS (thread = feature)
+  if (tid < H) {
+    prm[P_BC * H + tid] = b_c[tid];
+    prm[P_GE * H + tid] = g_e[tid];
+    prm[P_BE * H + tid] = b_e[tid];
+    prm[P_T * H + tid] = time_on_edge ? tbias[tid] : 0.0f;
+    prm[P_GO * H + tid] = g_o[tid];
+    prm[P_BO * H + tid] = b_o[tid];
+    prm[P_BOUT * H + tid] = b_out[tid];
+    if constexpr (L0) {
+      prm[P_TAB0 * H + tid] = l0_table[tid];
+      prm[P_TAB1 * H + tid] = l0_table[H + tid];
+      prm[P_CE0 * H + tid] = l0_table[2 * H + tid];
+      prm[P_CE1 * H + tid] = l0_table[3 * H + tid];
+    }
+  }
+  // layer 0: this lane's table row (float offset into prm), rule of table_rows_tiled_kernel
+  int l0_row = P_TAB0 * H;
+  if constexpr (L0) {
+    if (l0_x != nullptr && l0_x[l0_perm ? l0_perm[s] : s] > 0.5f) l0_row = P_TAB1 * H;
+  }
+  const int j = col[s];
+  const int i_node = row[s];
+  const float* nj = node4 + (long long)j * 4 * H;       // rows U | V | A | B
+  const float* ni = node4 + (long long)i_node * 4 * H;
+
+  if constexpr (kDma) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage 0 has landed
+  } else {
+    FUSED_STORE_STAGE(0)
+    FUSED_LOAD_STAGE(1)
+  }
+  __syncthreads();
+
+  FUSED_STAMP(1)
+  v16f acc1[8];
+  if constexpr (L0) {      // C e_in of this lane's features, from the row that belongs to its input row
+    const int ce_row = l0_row + (P_CE0 - P_TAB0) * H;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const v4f c = *reinterpret_cast<const v4f*>(prm + ce_row + 32 * nb + 8 * g + 4 * hh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc1[nb][4 * g + q] = c[q];
+      }
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.0f;
+  }
+
+  const int a_off = wslot(l31, hh);   // entry = 32 nb + l31 : (entry >> 3) & 1 == (l31 >> 3) & 1
+
+  // ================================ GEMM 1 ==========================================================
+#pragma unroll
+  for (int t = 0; t < (L0 ? 0 : NS1); ++t) {
+    FUSED_PIPE_BEGIN(t)
+    // B operands of the slab(s) of this stage
+    frag xh[SPS], xl[SPS];
+#pragma unroll
+    for (int sub = 0; sub < SPS; ++sub) {
+      const int ks = SPS * t + sub;
+      v4f c0, c1;
+      {
+        c0 = er[ks % RING][0];
+        c1 = er[ks % RING][1];
+        if (!kNoE && ks + RING < 16) {
+          er[ks % RING][0] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512 + loff);
+          er[ks % RING][1] = *reinterpret_cast<const v4f*>(etile + ((ks + RING) * 512 + 256) + loff);
+        }
+      }
+      const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      split8<T>(xs, xh[sub], xl[sub]);
+    }
+    // 8 SPS weight blocks (bi = sub * 8 + nb), A fragments read from LDS two blocks ahead of their MFMAs
+    const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
+    frag fh[4], fl[4];
+#define FUSED_FRAG1(bi, slot)                                                                        \
+  {                                                                                                  \
+    fh[slot] = *reinterpret_cast<const frag*>(wb + ((bi) >> 3) * 256 * 16 + ((bi) & 7) * 32 * 16);   \
+    fl[slot] = *reinterpret_cast<const frag*>(wb + PLANE + ((bi) >> 3) * 256 * 16 + ((bi) & 7) * 32 * 16); \
+  }
+    if constexpr ((OPT & 2) != 0) {
+      // pairs of blocks: fragments of pair bp + 1 are requested before the six MFMAs of pair bp, whose two accumulator
+      // chains alternate (per accumulator the order of the products is unchanged: bit-identical results)
+      FUSED_FRAG1(0, 0)
+      FUSED_FRAG1(1, 1)
+#pragma unroll
+      for (int bp = 0; bp < 4 * SPS; ++bp) {
+        if (bp + 1 < 4 * SPS) {
+          FUSED_FRAG1(2 * bp + 2, 2 * ((bp + 1) & 1))
+          FUSED_FRAG1(2 * bp + 3, 2 * ((bp + 1) & 1) + 1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int s0 = 2 * (bp & 1), s1 = s0 + 1, n0 = (2 * bp) & 7, n1 = n0 + 1, sub = (2 * bp) >> 3;
+        acc1[n0] = T::mfma(fl[s0], xh[sub], acc1[n0]);
+        acc1[n1] = T::mfma(fl[s1], xh[sub], acc1[n1]);
+        acc1[n0] = T::mfma(fh[s0], xl[sub], acc1[n0]);
+        acc1[n1] = T::mfma(fh[s1], xl[sub], acc1[n1]);
+        acc1[n0] = T::mfma(fh[s0], xh[sub], acc1[n0]);
+        acc1[n1] = T::mfma(fh[s1], xh[sub], acc1[n1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      FUSED_FRAG1(0, 0)
+      FUSED_FRAG1(1, 1)
+#pragma unroll
+      for (int bi = 0; bi < 8 * SPS; ++bi) {
+        if (bi + 2 < 8 * SPS) FUSED_FRAG1(bi + 2, (bi + 2) % 3)
+        __builtin_amdgcn_sched_barrier(0);
+        const int nb = bi & 7, sub = bi >> 3;
+        acc1[nb] = T::mfma(fl[bi % 3], xh[sub], acc1[nb]);
+        acc1[nb] = T::mfma(fh[bi % 3], xl[sub], acc1[nb]);
+        acc1[nb] = T::mfma(fh[bi % 3], xh[sub], acc1[nb]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef FUSED_FRAG1
+    FUSED_PIPE_END(t)
+    if (t == 0) { FUSED_STAMP(2) }
+    if (t == NS1 / 2 - 1) { FUSED_STAMP(3) }
+  }
+
+  FUSED_STAMP(4)
+  // ================================ epilogue 1 =======================================================
+  // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3.
+  // Neighbour-table rows are gathered one batch (= 2 quads) ahead of their use.
+  float s1 = 0.0f;
+  // segment structure of the tile: bit k of bnd = edge k starts a new centre node (wave uniform)
+  const int i_prev = __shfl_up(i_node, 1, 64);
+  const unsigned bnd = (unsigned)__ballot(l31 > 0 && i_node != i_prev);
+  const int first_end = bnd ? __builtin_ctz(bnd) : 32;
+  float* part0 = part + ((long long)tile * 2 + 0) * H;
+  float* part1 = part + ((long long)tile * 2 + 1) * H;
+
+  v4f ga[2][2][3];
+#define FUSED_GATHER(b, buf)                                                          \
+  {                                                                                   \
+    _Pragma("unroll") for (int q2 = 0; q2 < 2; ++q2) {                                \
+      const int fb_ = 32 * ((b) >> 1) + 8 * (2 * ((b) & 1) + q2) + 4 * hh;            \
+      if constexpr (!(ablate & 1) && !(ablate & 256)) {                               \
+        ga[buf][q2][0] = *reinterpret_cast<const v4f*>(nj + 2 * H + fb_);             \
+        if constexpr (TAIL != 1) ga[buf][q2][2] = *reinterpret_cast<const v4f*>(nj + H + fb_); \
+      } else {                                                                        \
+        ga[buf][q2][0] = ga[buf][q2][2] = v4f{0.f, 0.f, 0.f, 0.f};                    \
+      }                                                                               \
+      if constexpr (!(ablate & 1) && !(ablate & 128)) {                               \
+        ga[buf][q2][1] = *reinterpret_cast<const v4f*>(ni + 3 * H + fb_);             \
+      } else {                                                                        \
+        ga[buf][q2][1] = v4f{0.f, 0.f, 0.f, 0.f};                                     \
+      }                                                                               \
+    }                                                                                 \
+  }
+  FUSED_GATHER(0, 0)
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {             // batch b: block nb = b >> 1, quads g = 2 (b & 1) + {0, 1}
+    if (b + 1 < 16) {
+      if (((b + 1) & 1) == 0) FUSED_GATHER(b + 1, 0) else FUSED_GATHER(b + 1, 1)
+    }
+    const int nb = b >> 1, nq = nb & 1;
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      const int g = 2 * (b & 1) + q2;
+      const int fb = 32 * nb + 8 * g + 4 * hh;
+      const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
+      const v4f ah = ga[b & 1][q2][0], bh = ga[b & 1][q2][1], vh = ga[b & 1][q2][2];
+      v4f m;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float ce = acc1[nb][4 * g + q] + bc[q];
+        const float ev = (ah[q] + bh[q]) + ce;
+        acc1[nb][4 * g + q] = ev;
+        s1 += ev;
+        if constexpr (TAIL != 1) m[q] = valid ? fast_sigmoid(ev) * vh[q] : 0.0f;   // (select: pad lanes may hold anything)
+      }
+      if constexpr (TAIL != 1) *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
+    }
+    if (TAIL != 1 && (b & 3) == 3) {
+      // 64 features (blocks 2 rnd, 2 rnd + 1) of all 32 edges are in the scratch: segmented column sums,
+      // lane = feature 64 rnd + lane.  The first segment of a tile may continue from the previous tile and
+      // the last into the next one (part[tile][0|1]); inner segments are complete (direct[node]).
+      const int rnd = b >> 2;
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (!(ablate & 2)) {
+        const int f = 64 * rnd + lane;
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = scr[k * SCR_STRIDE + lane];
+        float accv = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          if (k > 0 && ((bnd >> k) & 1u)) {                      // wave-uniform branch
+            const int node = __builtin_amdgcn_readlane(i_node, k - 1);
+            float* dst = (k == first_end) ? part0 : direct + (long long)node * H;
+            dst[f] = accv;
+            accv = 0.0f;
+          }
+          accv += v[k];
+        }
+        float* dst = (first_end == 32) ? part0 : part1;
+        dst[f] = accv;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#undef FUSED_GATHER
+  FUSED_STAMP(5)
+  if constexpr (TAIL == 2) return;      // the edge output of this layer is never read
+
+  // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
+  constexpr float inv_h = 1.0f / 256.0f;
+  constexpr bool skip_math = (ablate & 4) != 0;
+  const float mean1 = skip_math ? 0.0f : (s1 + __shfl_xor(s1, 32, 64)) * inv_h;
+  float q1 = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = acc1[nb][r] - mean1;
+      acc1[nb][r] = d;
+      q1 += d * d;
+    }
+  const float rstd1 = __builtin_amdgcn_rsqf((q1 + __shfl_xor(q1, 32, 64)) * inv_h + 1e-5f);
+  float s2 = 0.0f;
+  if constexpr (!skip_math) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fb = 32 * nb + 8 * g + 4 * hh;
+        const v4f ge = *reinterpret_cast<const v4f*>(prm + P_GE * H + fb);
+        const v4f be = *reinterpret_cast<const v4f*>(prm + P_BE * H + fb);
+        const v4f tb = *reinterpret_cast<const v4f*>(prm + P_T * H + fb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float y = acc1[nb][4 * g + q] * rstd1 * ge[q] + be[q];
+          y = (y > 0.0f ? y : 0.0f) + tb[q];
+          acc1[nb][4 * g + q] = y;
+          s2 += y;
+        }
+      }
+  }
+  const float mean2 = (s2 + __shfl_xor(s2, 32, 64)) * inv_h;
+  float q2s = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = acc1[nb][r] - mean2;
+      acc1[nb][r] = d;
+      q2s += d * d;
+    }
+  const float rstd2 = __builtin_amdgcn_rsqf((q2s + __shfl_xor(q2s, 32, 64)) * inv_h + 1e-5f);
+
+  // activation -> 16-bit planes, kept in registers as the B operands of GEMM 2
+  frag ah_[8][2], al_[8][2];      // [block nb][register group rg] : slab 2 nb + rg
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+      float a8[8];
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        const int g = 2 * rg + g2;
+        const int fb = 32 * nb + 8 * g + 4 * hh;
+        const v4f go = *reinterpret_cast<const v4f*>(prm + P_GO * H + fb);
+        const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BO * H + fb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float z = acc1[nb][4 * g + q] * rstd2 * go[q] + bo[q];
+          a8[4 * g2 + q] = skip_math ? z : z * fast_sigmoid(z);
+        }
+      }
+      split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
+    }
+
+  FUSED_STAMP(6)
+  // ================================ GEMM 2 (four output quarters of 64 features) ======================
+  if constexpr (!kDma) { FUSED_LOAD_STAGE(NS1 + 1) }
+  constexpr bool skip_gemm2 = (ablate & 8) != 0;   // (barriers must still be executed by every wave)
+  constexpr bool skip_out = (ablate & 32) != 0;    // GEMM 2 without residual read / e store
+  constexpr bool skip_mm2 = (ablate & 64) != 0;    // GEMM 2 output path without its MFMAs
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    v16f acc2[2];
+#pragma unroll
+    for (int nbp = 0; nbp < 2; ++nbp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[nbp][r] = 0.0f;
+    v4f ein[2][4];      // residual rows of this quarter, fetched under the quarter's last 48 MFMAs
+#pragma unroll
+    for (int kc = 0; kc < SPQ; ++kc) {
+      const int t = NS1 + qt * SPQ + kc;
+      FUSED_PIPE_BEGIN(t)
+      if (kc == SPQ - 1 && !skip_gemm2 && !skip_out) {
+#pragma unroll
+        for (int nbp = 0; nbp < 2; ++nbp)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if constexpr (L0) ein[nbp][g] = *reinterpret_cast<const v4f*>(prm + l0_row + 64 * qt + 32 * nbp + 8 * g + 4 * hh);
+            else ein[nbp][g] = *reinterpret_cast<const v4f*>(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff);
+          }
+      }
+      const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
+      if constexpr (!skip_gemm2 && !skip_mm2) {
+        // 2 KPS weight blocks (bi = ksl * 2 + nbp), A fragments read from LDS two blocks ahead of their MFMAs
+        frag fh[4], fl[4];
+#define FUSED_FRAG2(bi, slot)                                                                            \
+  {                                                                                                      \
+    fh[slot] = *reinterpret_cast<const frag*>(wb + (((bi) >> 1) * 64 + ((bi) & 1) * 32) * 16);           \
+    fl[slot] = *reinterpret_cast<const frag*>(wb + PLANE + (((bi) >> 1) * 64 + ((bi) & 1) * 32) * 16);   \
+  }
+        if constexpr ((OPT & 2) != 0) {
+          // the two output blocks of a k slab alternate (independent accumulators acc2[0], acc2[1])
+          FUSED_FRAG2(0, 0)
+          FUSED_FRAG2(1, 1)
+#pragma unroll
+          for (int ksl = 0; ksl < KPS; ++ksl) {
+            if (ksl + 1 < KPS) {
+              FUSED_FRAG2(2 * ksl + 2, 2 * ((ksl + 1) & 1))
+              FUSED_FRAG2(2 * ksl + 3, 2 * ((ksl + 1) & 1) + 1)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int s0 = 2 * (ksl & 1), s1 = s0 + 1;
+            const int sl = KPS * kc + ksl;
+            acc2[0] = T::mfma(fl[s0], ah_[sl >> 1][sl & 1], acc2[0]);
+            acc2[1] = T::mfma(fl[s1], ah_[sl >> 1][sl & 1], acc2[1]);
+            acc2[0] = T::mfma(fh[s0], al_[sl >> 1][sl & 1], acc2[0]);
+            acc2[1] = T::mfma(fh[s1], al_[sl >> 1][sl & 1], acc2[1]);
+            acc2[0] = T::mfma(fh[s0], ah_[sl >> 1][sl & 1], acc2[0]);
+            acc2[1] = T::mfma(fh[s1], ah_[sl >> 1][sl & 1], acc2[1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          FUSED_FRAG2(0, 0)
+          FUSED_FRAG2(1, 1)
+#pragma unroll
+          for (int bi = 0; bi < 2 * KPS; ++bi) {
+            if (bi + 2 < 2 * KPS) FUSED_FRAG2(bi + 2, (bi + 2) % 3)
+            __builtin_amdgcn_sched_barrier(0);
+            const int ksl = bi >> 1, nbp = bi & 1;
+            const int sl = KPS * kc + ksl;        // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
+            acc2[nbp] = T::mfma(fl[bi % 3], ah_[sl >> 1][sl & 1], acc2[nbp]);
+            acc2[nbp] = T::mfma(fh[bi % 3], al_[sl >> 1][sl & 1], acc2[nbp]);
+            acc2[nbp] = T::mfma(fh[bi % 3], ah_[sl >> 1][sl & 1], acc2[nbp]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#undef FUSED_FRAG2
+      }
+      FUSED_PIPE_END(t)
+      if (t == NS1) { FUSED_STAMP(7) }
+    }
+    // e <- e + W_o a + b_o  for the features 64 qt + 32 nbp + 8 g + 4 hh + 0..3 of this lane's edge
+    if constexpr (skip_out) {
+#pragma unroll
+      for (int nbp = 0; nbp < 2; ++nbp) asm volatile("" ::"v"(acc2[nbp]));   // keep the MFMAs alive
+    }
+    float gs[8], gq[8];      // GNP: this lane's share of the 8 groups of the quarter
+#pragma unroll
+    for (int u = 0; u < 8; ++u) gs[u] = gq[u] = 0.0f;
+    if (valid && !skip_gemm2 && !skip_out) {
+#pragma unroll
+      for (int nbp = 0; nbp < 2; ++nbp)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int fo = 64 * qt + 32 * nbp + 8 * g + 4 * hh;
+          const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BOUT * H + fo);
+          v4f v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
+          *reinterpret_cast<v4f*>(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff) = v;
+          if constexpr (GNP) {
+            gs[nbp * 4 + g] = (v[0] + v[1]) + (v[2] + v[3]);
+            gq[nbp * 4 + g] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          }
+        }
+    }
+    if constexpr (GNP) {     // all lanes again: 16 wave sums, lane 0 writes the quarter's 8 (sum, sum of squares) pairs
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wave_sum2(gs[u], gq[u]);
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; u += 2)
+          *reinterpret_cast<v4f*>(gn_tile + (long long)tile * 64 + qt * 16 + 2 * u) = v4f{gs[u], gq[u], gs[u + 1], gq[u + 1]};
+      }
+    }
+    if (qt == 0) { FUSED_STAMP(8) }
+  }
+  FUSED_STAMP(9)
+  if constexpr ((ABL & 16) != 0) {
+    if (dbg != nullptr && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) dbg[((long long)blockIdx.x * WAVES + wave) * 16 + k] = stamp[k];
+    }
+  }
+#undef FUSED_STAMP
+#undef FUSED_LOAD_STAGE
+#undef FUSED_STORE_STAGE
+#undef FUSED_PIPE_BEGIN
+#undef FUSED_PIPE_END
+#undef FUSED_DMA_STAGE
+}
+
+#define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
+
+template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0, int OPT = 0>
+hipError_t launch_fused_t(float* e, const float* node4, const int* row, const int* col, int n_edges,
+                                 const unsigned short* c_planes, const unsigned short* o_planes, long long plane_stride,
+                                 const float* b_c, const float* g_e, const float* b_e, const float* tbias,
+                                 const float* g_o, const float* b_o, const float* b_out, int time_on_edge, float* part,
+                                 float* direct, hipStream_t stream, const float* l0_table = nullptr,
+                                 const float* l0_x = nullptr, const int* l0_perm = nullptr, float* gn_tile = nullptr) {
+  static std::atomic<unsigned long long> attr_devices{0};      // per kernel instantiation: devices already configured
+  {
+    hipError_t er = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL, OPT>),
+                                           160 * 1024);
+    if (er != hipSuccess) return er;
+  }
+  constexpr int WV = fused::geo_waves(NW);
+  const unsigned grid = (unsigned)((n_edges + 32 * WV - 1) / (32 * WV));
+  // profiling: g_fused_lds_pad extra bytes of dynamic LDS lower the number of co-resident workgroups per CU
+  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL, OPT>), dim3(grid), dim3(64 * WV),
+                     fused::Geo<NW>::LDS_TOTAL + g_fused_lds_pad, stream,
+                     e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
+                     time_on_edge, part, direct, g_fused_dbg, l0_table, l0_x, l0_perm, gn_tile);
+  return hipGetLastError();
+}
+
+// production geometry, no ablation; the scheduling options come from g_fused_opt (bit-identical results)
+template <typename T, bool L0, bool GNP, int TAIL, typename... A>
+hipError_t launch_fused_opt(A... args) {
+  switch (g_fused_opt) {
+    case 1: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 1>(args...);
+    case 2: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 2>(args...);
+    case 3: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 3>(args...);
+    default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 0>(args...);
+  }
+}
+
+// one entry point per element type / purpose, each defined in its own translation unit.
+// kind: 0 middle layer, 1 first layer from the 2-row table (L0), 2 last layer of a TSP step (GNP, TAIL 1),
+//       3 last layer of a MIS step (TAIL 2)
+#define FUSED_KIND_PARAMS                                                                                              \
+  float *e, const float *node4, const int *row, const int *col, int n_edges, const unsigned short *c_planes,          \
+      const unsigned short *o_planes, long long plane_stride, const float *b_c, const float *g_e, const float *b_e,   \
+      const float *tbias, const float *g_o, const float *b_o, const float *b_out, int time_on_edge, float *part,      \
+      float *direct, hipStream_t stream, const float *l0_table, const float *l0_x, const int *l0_perm, float *gn_tile
+#define FUSED_KIND_ARGS                                                                                                \
+  e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, \
+      part, direct, stream, l0_table, l0_x, l0_perm, gn_tile
+hipError_t launch_fused_fp16(int kind, FUSED_KIND_PARAMS);
+hipError_t launch_fused_bf16(int kind, FUSED_KIND_PARAMS);
+hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS);      // profiling-only variants of the fp16 middle layer
+
+template <typename T>
+hipError_t launch_fused_kind(int kind, FUSED_KIND_PARAMS) {
+  switch (kind) {
+    case 0: return launch_fused_opt<T, false, false, 0>(FUSED_KIND_ARGS);
+    case 1: return launch_fused_opt<T, true, false, 0>(FUSED_KIND_ARGS);
+    case 2: return launch_fused_opt<T, false, true, 1>(FUSED_KIND_ARGS);
+    case 3: return launch_fused_opt<T, false, false, 2>(FUSED_KIND_ARGS);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace difusco

@@ -2,7 +2,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 namespace difusco {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): `devices` is the per-kernel bit mask of the
+// devices already configured.  Thread safe (setting the attribute twice is harmless).
+inline hipError_t ensure_max_dynamic_lds(std::atomic<unsigned long long>& devices, const void* fn, int bytes) {
+  int dev = 0;
+  hipError_t er = hipGetDevice(&dev);
+  if (er != hipSuccess) return er;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (devices.load(std::memory_order_acquire) & bit) return hipSuccess;
+  er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (er != hipSuccess) return er;
+  devices.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
 
 // sets the message returned by difusco_last_error() and returns `code` (api.hip)
 int set_error(int code, const char* fmt, ...);
@@ -49,13 +65,7 @@ hipError_t launch_edge_layer_fused_tail(int mode, int tail, float* e, const floa
                                         int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream);
 extern int g_fused_gn_fold;
 extern int g_fused_lds_pad;
-// software-pipelined persistent variant of the same layer (edge_layer_pipe.hip); same arguments and results
-hipError_t launch_edge_layer_pipe(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
-                                  const unsigned short* c_planes, const unsigned short* o_planes,
-                                  long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
-                                  const float* tbias, const float* g_o, const float* b_o, const float* b_out,
-                                  int time_on_edge, float* part, float* direct, hipStream_t stream);
-extern int g_fused_variant;   // 0: edge_layer_fused_kernel, 1: edge_layer_pipe_kernel
+extern int g_fused_opt;
 extern unsigned long long* g_fused_dbg;
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,

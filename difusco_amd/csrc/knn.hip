@@ -161,12 +161,10 @@ int difusco_knn_graph(int n_nodes, int k, const double* points, int64_t node_off
   const size_t fixed = (knn_fixed_lds(k) + 15) / 16 * 16;
   if (n_nodes <= KNN_LDS_POINTS) {
     const size_t lds = fixed + (size_t)n_nodes * 8;
-    static bool attr = false;
-    if (!attr) {
-      hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static std::atomic<unsigned long long> attr_devices{0};      // per device (a process-wide flag skipped device 2+)
+    {
+      hipError_t er = difusco::ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&knn_kernel<true>), 160 * 1024);
       if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "knn_graph: %s", hipGetErrorString(er));
-      attr = true;
     }
     hipLaunchKernelGGL(knn_kernel<true>, dim3(n_nodes), dim3(KNN_THREADS), lds, st, points, n_nodes, k,
                        (long long)node_offset, (long long*)edge_row0, (long long*)edge_row1, (unsigned long long*)nullptr);

@@ -18,6 +18,7 @@
 //     16-byte bank slots (stride 36 or 20 dwords -> row*9 or row*5 mod 16 distinct).
 //   * global -> LDS through registers, next slab prefetched while the current one is multiplied.
 #include "common.h"
+#include "kernels.h"
 
 namespace difusco {
 
@@ -151,12 +152,10 @@ template <int K, int FB, int BK>
 static hipError_t launch_linear(const float* x, const float* w, const float* bias, const float* residual, float* y,
                                 long long m, int n_out, long long ldy, hipStream_t stream) {
   constexpr size_t lds = (size_t)(128 + FB) * (BK + 4) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_kernel<K, FB, BK>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static std::atomic<unsigned long long> attr_devices{0};
+  {
+    hipError_t e = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&linear_rows_kernel<K, FB, BK>), (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   dim3 grid((unsigned)((m + 127) / 128), (unsigned)(n_out / FB));
   hipLaunchKernelGGL((linear_rows_kernel<K, FB, BK>), grid, dim3(256), lds, stream, x, w, bias, residual, y, m, ldy);

@@ -67,6 +67,8 @@ class DenoiseEngine:
             points = points.to(dev, dtype=torch.float32).contiguous()
             if points.numel() != 2 * g.n_nodes:
                 raise ValueError("points must be [n_nodes, 2]")
+            if g.node_order is not None:          # the graph numbers its nodes for locality (graph.build_csr)
+                points = points.reshape(-1, 2).index_select(0, g.node_order)
         draws = float(post[4]) != 0.0
         if rand is not None:
             rand = rand.to(dev, dtype=torch.float32).contiguous().reshape(-1)

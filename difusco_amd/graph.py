@@ -27,6 +27,10 @@ class CsrGraph:
     row: Optional[torch.Tensor] = None       # int32 [n_edges] centre node of each CSR slot, device
     seg_ptr: Optional[torch.Tensor] = None   # int32 [S+1] device; GroupNorm statistic segments
     n_segments: int = 1
+    # internal node id -> caller node id (int64, device) when the nodes were renumbered for locality (TSP: Morton order
+    # of the coordinates inside every graph of the batch); None = caller numbering.  Only node-indexed INPUTS (points)
+    # have to be gathered with it; outputs of a TSP step are per edge and go through ``perm``.
+    node_order: Optional[torch.Tensor] = None
 
 
 def csr_from_coo_host(edge_index: np.ndarray, n_nodes: int):
@@ -45,14 +49,72 @@ def csr_from_coo_host(edge_index: np.ndarray, n_nodes: int):
     return rowptr, col, row, perm, bool(ident.value)
 
 
-def build_csr(edge_index: torch.Tensor, n_nodes: int, device, seg_rows: Optional[np.ndarray] = None) -> CsrGraph:
+def _id_blocks(rowptr: np.ndarray, col: np.ndarray, n_nodes: int) -> np.ndarray:
+    """Block id per node of the finest partition of 0..n-1 into CONTIGUOUS id ranges that no edge crosses - for a
+    disjoint-union batch (``pl_meta_model.py:177-184``) these are the graphs of the batch (or unions of them)."""
+    deg = np.diff(rowptr)
+    ids = np.arange(n_nodes, dtype=np.int64)
+    lo, hi = ids.copy(), ids.copy()
+    nz = np.flatnonzero(deg > 0)
+    if nz.size:
+        starts = rowptr[nz].astype(np.int64)
+        lo[nz] = np.minimum(lo[nz], np.minimum.reduceat(col, starts))
+        hi[nz] = np.maximum(hi[nz], np.maximum.reduceat(col, starts))
+    reach = np.maximum.accumulate(hi)                  # furthest id touched by the nodes 0..i
+    back = np.minimum.accumulate(lo[::-1])[::-1]       # lowest id touched by the nodes i..n-1
+    cut = np.zeros(n_nodes, dtype=np.int64)            # cut[b] = 1: a block starts at node b
+    if n_nodes > 1:
+        cut[1:] = (reach[:-1] < ids[1:]) & (back[1:] >= ids[1:])
+    return np.cumsum(cut)
+
+
+def _morton_keys(points: np.ndarray) -> np.ndarray:
+    """Z-order key of 2-D points (16 bits per axis over the bounding box)."""
+    p = np.asarray(points, dtype=np.float64).reshape(-1, 2)
+    mn, mx = p.min(axis=0), p.max(axis=0)
+    q = np.clip((p - mn) / np.maximum(mx - mn, 1e-30) * 65535.0, 0, 65535).astype(np.uint64)
+
+    def spread(v):
+        v = (v | (v << 8)) & np.uint64(0x00FF00FF)
+        v = (v | (v << 4)) & np.uint64(0x0F0F0F0F)
+        v = (v | (v << 2)) & np.uint64(0x33333333)
+        return (v | (v << 1)) & np.uint64(0x55555555)
+
+    return spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1))
+
+
+def locality_node_order(rowptr: np.ndarray, col: np.ndarray, points: np.ndarray) -> np.ndarray:
+    """new -> old node numbering: inside every graph of the batch (see :func:`_id_blocks`) the nodes are sorted along
+    the Morton curve of their coordinates.  Spatially close centre nodes then sit in neighbouring CSR rows, and since
+    k-NN neighbours are spatially close too, the rows A h[j], V h[j] gathered by consecutive 32-edge tiles are a small
+    compact set (L2-resident per XCD with the XCD-contiguous tile ranges of the fused kernel)."""
+    n = rowptr.shape[0] - 1
+    return np.lexsort((_morton_keys(points), _id_blocks(rowptr, col, n))).astype(np.int64)
+
+
+def build_csr(edge_index: torch.Tensor, n_nodes: int, device, seg_rows: Optional[np.ndarray] = None,
+              points=None) -> CsrGraph:
     """edge_index int64 [2,E] (any device).  ``seg_rows``: boundaries [S+1] of the head-GroupNorm
-    statistic segments over output rows (None = one segment = the reference's sparse behaviour)."""
-    rowptr, col, _row, perm, ident = csr_from_coo_host(edge_index.detach().cpu().numpy(), n_nodes)
+    statistic segments over output rows (None = one segment = the reference's sparse behaviour).
+    ``points`` ([n_nodes,2], optional): renumber the nodes for locality (``locality_node_order``); invisible to the
+    caller - edge outputs keep the caller's edge order through ``perm``, ``node_order`` gathers the point input."""
+    ei = edge_index.detach().cpu().numpy()
+    rowptr, col, _row, perm, ident = csr_from_coo_host(ei, n_nodes)
+    order = None
+    if points is not None and n_nodes > 1 and col.shape[0] > 0:
+        pts = points.detach().cpu().numpy() if isinstance(points, torch.Tensor) else np.asarray(points)
+        order = locality_node_order(rowptr, col, pts.reshape(-1, 2)[:n_nodes])
+        if np.array_equal(order, np.arange(n_nodes)):
+            order = None
+        else:
+            inv = np.empty(n_nodes, dtype=np.int64)
+            inv[order] = np.arange(n_nodes, dtype=np.int64)
+            rowptr, col, _row, perm, ident = csr_from_coo_host(inv[np.ascontiguousarray(ei, dtype=np.int64)], n_nodes)
     g = CsrGraph(
         n_nodes=n_nodes, n_edges=int(col.shape[0]),
         rowptr=torch.from_numpy(rowptr).to(device), col=torch.from_numpy(col).to(device),
-        perm=None if ident else torch.from_numpy(perm).to(device), row=torch.from_numpy(_row).to(device))
+        perm=None if ident else torch.from_numpy(perm).to(device), row=torch.from_numpy(_row).to(device),
+        node_order=None if order is None else torch.from_numpy(order).to(device))
     if seg_rows is not None and len(seg_rows) > 2:
         g.seg_ptr = torch.from_numpy(np.asarray(seg_rows, dtype=np.int32)).to(device)
         g.n_segments = len(seg_rows) - 1

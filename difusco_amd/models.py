@@ -44,7 +44,7 @@ class COMetaModel:
 
     def __init__(self, param_args=None, state_dict=None, node_feature_only=False, device="cuda:0",
                  seed: Optional[int] = None, engine: Optional[DenoiseEngine] = None, precision: str = "fp16x3",
-                 fused: bool = True, gn_reduce=None):
+                 fused: bool = True, gn_reduce=None, reorder_nodes: bool = True):
         args = dict(_DEFAULTS)
         if param_args is not None:
             args.update(vars(param_args) if not isinstance(param_args, dict) else param_args)
@@ -75,20 +75,25 @@ class COMetaModel:
         self.device = engine.device
         self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
         self._graph_cache = {}
+        self.reorder_nodes = reorder_nodes      # TSP: Morton-order the nodes of every graph for L2 locality (graph.py)
         # optional: shard-summing callable for the head GroupNorm statistics (difusco_amd.dist.gn_allreduce); None =
         # statistics of each call's own rows, the reference's behaviour for that call
         self.gn_reduce = gn_reduce
 
     # ---- graph handling --------------------------------------------------------------------------
-    def prepare_graph(self, edge_index: torch.Tensor, num_nodes: int) -> CsrGraph:
+    def prepare_graph(self, edge_index: torch.Tensor, num_nodes: int, points=None) -> CsrGraph:
         """COO -> CSR once per instance; cached on the identity of ``edge_index`` so the 50 calls of
-        a sampling loop convert once."""
-        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes))
+        a sampling loop convert once.  ``points`` (TSP): lets the graph renumber its nodes along a space-filling
+        curve (``graph.locality_node_order``) - a pure locality choice, valid for any coordinates, invisible outside.
+        Tensors created under ``torch.inference_mode()`` (Lightning's default for ``trainer.test``) have no version
+        counter: for those the key is the storage address alone, which the cache keeps alive."""
+        version = 0 if edge_index.is_inference() else edge_index._version
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), version, int(num_nodes))
         g = self._graph_cache.get(key)
         if g is None:
             if len(self._graph_cache) > 8:
                 self._graph_cache.clear()
-            g = build_csr(edge_index, int(num_nodes), self.device)
+            g = build_csr(edge_index, int(num_nodes), self.device, points=points if self.reorder_nodes else None)
             self._graph_cache[key] = (g, edge_index)   # keep edge_index alive: data_ptr stays unique
             return g
         return g[0]
@@ -145,7 +150,7 @@ class TSPModel(COMetaModel):
 
     def _graph_and_inputs(self, points, xt, edge_index):
         if edge_index is not None:
-            g = self.prepare_graph(edge_index, points.shape[0])
+            g = self.prepare_graph(edge_index, points.shape[0], points=points)
             return g, points.reshape(-1, 2), xt.reshape(-1), None
         if points.dim() != 3:
             raise ValueError("dense mode expects points [B,V,2] and xt [B,V,V]")

@@ -273,10 +273,13 @@ int difusco_profile_enable(int on, int max_launches);
 /* Profiling knobs, never used in production.  key 0: ablation mask of the fused edge-layer kernel
  * (bit0 skip neighbour-table gathers, bit1 skip the neighbour sum, bit2 skip LN/activation math,
  * bit3 skip GEMM 2) - results are WRONG with a non-zero mask; only kernel time is meaningful. */
-int difusco_debug_set(int key, int value);   /* key 2: 1 = software-pipelined fused kernel variant; key 3: 0 = do not
+int difusco_debug_set(int key, int value);   /* key 3: 0 = do not
                                               * fold the first layer's table lookup into the fused kernel (A/B);
                                               * key 4: 0 = head statistics by a separate pass over e (A/B);
-                                              * key 6: extra dynamic LDS bytes for the fused kernel (occupancy probe) */
+                                              * key 6: extra dynamic LDS bytes for the fused kernel (occupancy probe);
+                                              * key 7: scheduling options of the fused kernel (bit 0 XCD-contiguous
+                                              * tile ranges, bit 1 alternating MFMA accumulator chains; results are
+                                              * bit-identical for every value) */
 /* key 1: device buffer [n_tiles][8] of uint64 receiving s_memtime stamps of the fused kernel's phases
  * (NULL disables; profiling only). */
 int difusco_debug_set_ptr(int key, void* p);

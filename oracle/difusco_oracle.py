@@ -451,6 +451,17 @@ def init_params(hidden: int, n_layers: int, out_channels: int, seed: int,
     return p
 
 
+def params_sha256(p: Params) -> str:
+    """SHA-256 over the (sorted) names and fp32 bytes of a parameter dict: fixtures whose weights are regenerated
+    from a seed (tests/golden/make_golden_h256.py) carry this hash so that an RNG change cannot go unnoticed."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(p):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(p[k].detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
 def knn_graph(points: np.ndarray, k: int) -> np.ndarray:
     """Row-sorted constant-degree k-NN edge list including self as nearest neighbour, neighbours in
     distance order - the layout TSPGraphDataset produces (co_datasets/tsp_graph_dataset.py:53-62).

@@ -13,9 +13,14 @@ from difusco_amd import _lib, graph, synthetic, weights  # noqa: E402
 dev = torch.device("cuda:0")
 H, N1, K, G = 256, 1000, 100, 8
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp16x3"
-masks = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 8, 15, 100]
+# variants: "<ablation mask>" or "<mask>/<opt>" (opt = difusco_debug_set key 7: bit 0 XCD ranges, bit 1 MFMA chains)
+def _var(v):
+    a, _, o = v.partition("/")
+    return (int(a), int(o or 0))
+masks = [_var(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [(0, 0), (0, 1), (0, 2), (0, 3), (15, 0), (17, 0)]
 pts, ei = synthetic.tsp_batch(N1, K, range(G))
-g = graph.build_csr(ei, N1 * G, dev)
+g = graph.build_csr(ei, N1 * G, dev, points=pts if os.environ.get("NODE_ORDER", "morton") == "morton" else None)
+print("node order:", "morton" if g.node_order is not None else "caller")
 E, N = g.n_edges, g.n_nodes
 gen = torch.Generator().manual_seed(0)
 node4 = torch.randn(N, 4 * H, generator=gen).to(dev)
@@ -45,7 +50,8 @@ times = {m: [] for m in masks}
 e, h = e0.clone(), h0.clone()
 for r in range(ROUNDS + 1):
     for mask in masks:
-        L.difusco_debug_set(0, mask)
+        L.difusco_debug_set(0, mask[0])
+        L.difusco_debug_set(7, mask[1])
         run(e, h)
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -59,26 +65,21 @@ for r in range(ROUNDS + 1):
 for mask in masks:
     ts = sorted(times[mask])
     ms = ts[len(ts) // 2]
-    print(f"{prec} ablate={mask:3d}: median {ms:.3f} ms  min {ts[0]:.3f}  max {ts[-1]:.3f} per layer  (E={E}, "
+    print(f"{prec} ablate/opt={mask}: median {ms:.3f} ms  min {ts[0]:.3f}  max {ts[-1]:.3f} per layer  (E={E}, "
           f"{2*E*H*4/ms/1e6:.0f} GB/s algorithmic, {4*E*H*H*3/ms/1e9:.0f} TF issued)")
 L.difusco_debug_set(0, 0)
-# the two workgroup geometries must give the same result (same arithmetic, same tile decomposition)
+L.difusco_debug_set(7, 0)
+# the scheduling options must not change a single bit
 outs = []
-for mask in (0, 100):
-    L.difusco_debug_set(0, mask)
+for opt in (0, 1, 2, 3):
+    L.difusco_debug_set(7, opt)
     e, h = e0.clone(), h0.clone()
     run(e, h)
     torch.cuda.synchronize()
     outs.append((e, h))
-L.difusco_debug_set(0, 0)
-print("geometry A/B max |diff| e, h:", (outs[0][0] - outs[1][0]).abs().max().item(), (outs[0][1] - outs[1][1]).abs().max().item())
-for mask in [int(m) for m in os.environ.get("CMP_MASKS", "").split(",") if m]:     # variants that must not change results
-    L.difusco_debug_set(0, mask)
-    e, h = e0.clone(), h0.clone()
-    run(e, h)
-    torch.cuda.synchronize()
-    L.difusco_debug_set(0, 0)
-    print(f"variant {mask} vs production max |diff| e, h:", (outs[0][0] - e).abs().max().item(), (outs[0][1] - h).abs().max().item())
+L.difusco_debug_set(7, 0)
+for opt in (1, 2, 3):
+    print(f"opt {opt} vs opt 0: bit-identical e {torch.equal(outs[0][0], outs[opt][0])}, h {torch.equal(outs[0][1], outs[opt][1])}")
 if len(sys.argv) > 3 and sys.argv[3] == 'nostamp':
     sys.exit(0)
 # phase timestamps (s_memtime, 100 MHz-class constant clock or shader clock - reported as raw ticks and as shares)

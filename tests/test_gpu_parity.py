@@ -723,3 +723,219 @@ def test_global_groupnorm_statistics_over_shards(dev, fused):
     print(f"sharded vs whole-batch logits: global statistics {e_glob:.2e}, per-shard statistics {e_loc:.2e}")
     assert e_glob < 2e-5
     assert e_loc > 10 * e_glob          # per-shard statistics are a different (documented) composition
+
+
+# ------------------------------------------------------------------------------------------------
+# production width against REFERENCE-generated fixtures (tests/golden/make_golden_h256.py): H=256 is the only width
+# the fused edge-layer kernel exists for, so these are the fixtures that pin the DEFAULT product path directly.
+# ------------------------------------------------------------------------------------------------
+def _h256_cat(z, n_steps, step):
+    worst = 0.0
+    for i in range(n_steps):
+        t, tt = (int(v) for v in z[f"cat{i}_t"])
+        u = torch.from_numpy(z[f"cat{i}_uniform"]) if f"cat{i}_uniform" in z.files else None
+        out, logits, prob = step(torch.from_numpy(z[f"cat{i}_xt"]), t, tt, u)
+        worst = max(worst, _check_cat(z, i, out, logits, prob))
+    return worst
+
+
+def _h256_gau(z, n_steps, step):
+    worst = 0.0
+    for i in range(n_steps):
+        t, tt = (int(v) for v in z[f"gau{i}_t"])
+        out, pred = step(torch.from_numpy(z[f"gau{i}_xt"]), t, tt)
+        ref = z[f"gau{i}_pred"].squeeze(1)
+        e = np.abs(pred.cpu().numpy().reshape(ref.shape) - ref).max()
+        assert e < TOL and np.abs(out.cpu().numpy().reshape(z[f"gau{i}_out"].shape) - z[f"gau{i}_out"]).max() < TOL
+        worst = max(worst, e)
+    return worst
+
+
+@pytest.mark.parametrize("prec", ["fp16x3", "bf16x3", "fp16x3/unfused", "fp32"])
+def test_golden_h256_tsp_dense_one_sample(dev, prec):
+    """Pure reference arithmetic (tier B, no substitute code anywhere) at H=256 with ONE sample: a single GroupNorm
+    statistic segment, so the default engine runs the FUSED kernel on the complete-graph CSR."""
+    from conftest import load_h256_fixture
+    from difusco_amd import TSPModel
+    z, cat, gau = load_h256_fixture("tsp_dense_h256_l3_b1.npz")
+    pts = torch.from_numpy(z["points"]).to(dev)
+    m = TSPModel(_args("categorical", sparse_factor=-1, H=256, L=3), cat, device=dev, **_prec(prec))
+    e1 = _h256_cat(z, 3, lambda xt, t, tt, u: m.categorical_denoise_step(pts, xt.to(dev), np.array([t]), dev, None,
+                                                                        target_t=np.array([tt]), uniform=u, return_aux=True))
+    mg = TSPModel(_args("gaussian", sparse_factor=-1, H=256, L=3), gau, device=dev, **_prec(prec))
+    e2 = _h256_gau(z, 2, lambda xt, t, tt: mg.gaussian_denoise_step(pts, xt.to(dev), np.array([t]), dev, None,
+                                                                   target_t=np.array([tt]), return_aux=True))
+    print(f"H=256 dense B=1 {prec}: logits L_inf {e1:.2e}, eps L_inf {e2:.2e} vs the imported reference")
+
+
+@pytest.mark.parametrize("prec", ["fp16x3", "bf16x3", "fp16x3/unfused", "fp32"])
+@pytest.mark.parametrize("G", [1, 3])
+def test_golden_h256_tsp_sparse(dev, G, prec):
+    from conftest import load_h256_fixture
+    from difusco_amd import TSPModel
+    z, cat, gau = load_h256_fixture(f"tsp_sparse_h256_l3_g{G}.npz")
+    K = int(z["k"])
+    pts, ei = torch.from_numpy(z["points"]).to(dev), torch.from_numpy(z["edge_index"]).to(dev)
+    m = TSPModel(_args("categorical", K, H=256, L=3), cat, device=dev, **_prec(prec))
+    e1 = _h256_cat(z, 4, lambda xt, t, tt, u: m.categorical_denoise_step(pts, xt.to(dev), np.array([t]), dev, ei,
+                                                                        target_t=np.array([tt]),
+                                                                        uniform=None if u is None else u.reshape(-1),
+                                                                        return_aux=True))
+    mg = TSPModel(_args("gaussian", K, H=256, L=3), gau, device=dev, **_prec(prec))
+    e2 = _h256_gau(z, 2, lambda xt, t, tt: mg.gaussian_denoise_step(pts, xt.to(dev), np.array([t]), dev, ei,
+                                                                   target_t=np.array([tt]), return_aux=True))
+    print(f"H=256 sparse G={G} {prec}: logits L_inf {e1:.2e}, eps L_inf {e2:.2e} vs the imported reference")
+
+
+@pytest.mark.parametrize("prec", ["fp16x3", "bf16x3", "fp16x3/unfused", "fp32"])
+def test_golden_h256_mis(dev, prec):
+    from conftest import load_h256_fixture
+    from difusco_amd import MISModel
+    z, cat, gau = load_h256_fixture("mis_sparse_h256_l3.npz")
+    ei = torch.from_numpy(z["edge_index"]).to(dev)
+    m = MISModel(_args("categorical", -1, H=256, L=3), cat, device=dev, **_prec(prec))
+    e1 = _h256_cat(z, 3, lambda xt, t, tt, u: m.categorical_denoise_step(xt.to(dev), np.array([t]), dev, ei,
+                                                                        target_t=np.array([tt]),
+                                                                        uniform=None if u is None else u.reshape(-1),
+                                                                        return_aux=True))
+    mg = MISModel(_args("gaussian", -1, H=256, L=3), gau, device=dev, **_prec(prec))
+    e2 = _h256_gau(z, 2, lambda xt, t, tt: mg.gaussian_denoise_step(xt.to(dev), np.array([t]), dev, ei,
+                                                                   target_t=np.array([tt]), return_aux=True))
+    print(f"H=256 MIS {prec}: logits L_inf {e1:.2e}, eps L_inf {e2:.2e} vs the imported reference")
+
+
+# ------------------------------------------------------------------------------------------------
+# the BENCHED configuration: TSP-1000, K=100, H=256, 12 layers (BASELINE configs[2], 8 graphs per GPU)
+# ------------------------------------------------------------------------------------------------
+def test_bench_workload_tsp1000_oracle_and_batch(dev):
+    """(1) ONE TSP-1000 / K=100 graph, one teacher-forced step through the default engine against the CPU oracle
+    (E = 100,000 rows: the oracle needs ~10-30 s).  (2) The benched call shape, 8 graphs = 800,000 edges: bitwise
+    determinism; with 8 replicas of that graph every replica's rows are bitwise equal (100,000 edges = 3,125 whole
+    32-edge tiles, so each replica sees the same tile alignment) and, replicated data having the statistics of one
+    copy, equal to the single-graph call to fp32 summation accuracy - which (1) ties to the oracle.  (3) Eight DISTINCT
+    graphs: fused == unfused kernel sequence at full size."""
+    from difusco_amd import TSPModel
+    from difusco_amd.synthetic import tsp_batch
+    H, Lyr, N, K, G = 256, 12, 1000, 100, 8
+    p = O.init_params(H, Lyr, 2, seed=20240926)
+    pts1, ei1 = O.tsp_instance(N, K, seed=1000)
+    pts1, ei1 = torch.from_numpy(pts1), torch.from_numpy(ei1)
+    E1 = ei1.shape[1]
+    g = torch.Generator().manual_seed(12)
+    xt1 = (torch.randn(E1, generator=g) > 0).float()
+    u1 = torch.rand(E1, generator=g)
+    t, tt = 500, 469
+    ref_out, ref_logits, ref_prob = O.tsp_categorical_denoise_step(p, O.CategoricalTables(), pts1, xt1, t, ei1, tt,
+                                                                   uniform=u1, return_aux=True)
+    m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev)          # default engine: fused, fp16x3
+    out1, l1, p1 = m.categorical_denoise_step(pts1.to(dev), xt1.to(dev), np.array([t]), dev, ei1.to(dev),
+                                              target_t=np.array([tt]), uniform=u1, return_aux=True)
+    e_log, e_prob = (l1.cpu() - ref_logits).abs().max().item(), (p1.cpu() - ref_prob.reshape(-1)).abs().max().item()
+    print(f"TSP-1000 K=100 H=256 L=12, one graph vs oracle: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
+    assert e_log < TOL and e_prob < TOL
+    safe = (u1 - ref_prob.reshape(-1)).abs() > 1e-4
+    assert torch.equal(out1.cpu()[safe], ref_out[safe])
+    # (2) the benched call shape with replicas
+    pts = pts1.repeat(G, 1).to(dev)
+    ei = O.duplicate_edge_index(ei1, N, G).to(dev)
+    xt, u = xt1.repeat(G).to(dev), u1.repeat(G)
+    a, la, pa = m.categorical_denoise_step(pts, xt, np.array([t]), dev, ei, target_t=np.array([tt]), uniform=u, return_aux=True)
+    b, lb, pb = m.categorical_denoise_step(pts, xt, np.array([t]), dev, ei, target_t=np.array([tt]), uniform=u, return_aux=True)
+    assert torch.equal(a, b) and torch.equal(la, lb) and torch.isfinite(la).all()
+    la = la.reshape(G, E1, 2)
+    for k in range(1, G):
+        assert torch.equal(la[0], la[k])
+    e_rep = (la[0] - l1).abs().max().item()
+    print(f"8 replicas vs the single-graph call: logits L_inf {e_rep:.3e}")
+    assert e_rep < 2e-5
+    # (3) eight distinct graphs (the bench's instances), fused vs unfused
+    ptsd, eid = tsp_batch(N, K, range(G), device=dev)
+    gd = torch.Generator().manual_seed(13)
+    xtd = (torch.randn(eid.shape[1], generator=gd) > 0).float().to(dev)
+    ud = torch.rand(eid.shape[1], generator=gd)
+    mu = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev, fused=False)
+    _, lf, pf = m.categorical_denoise_step(ptsd, xtd, np.array([t]), dev, eid, target_t=np.array([tt]), uniform=ud, return_aux=True)
+    _, lu, pu = mu.categorical_denoise_step(ptsd, xtd, np.array([t]), dev, eid, target_t=np.array([tt]), uniform=ud, return_aux=True)
+    e_fu = (lf - lu).abs().max().item()
+    print(f"8 distinct TSP-1000 graphs: fused vs unfused logits L_inf {e_fu:.3e}")
+    assert e_fu < 5e-5 and (pf - pu).abs().max().item() < 5e-5
+
+
+def test_bench_workload_tsp500_x16_and_mis_x16(dev):
+    """The per-GPU shards of BASELINE configs[1] / configs[3] at their full batch: TSP-500 K=50 x 16 graphs and
+    16 Erdos-Renyi graphs n in [700,800]: determinism, finiteness, {0,1} outputs, fused == unfused."""
+    from difusco_amd import MISModel, TSPModel
+    from difusco_amd.synthetic import er_mis_edge_index, tsp_batch
+    H, Lyr = 256, 12
+    t, tt = np.array([500]), np.array([469])
+    p = O.init_params(H, Lyr, 2, seed=2)
+    pts, ei = tsp_batch(500, 50, range(16), device=dev)
+    g = torch.Generator().manual_seed(14)
+    xt = (torch.randn(ei.shape[1], generator=g) > 0).float().to(dev)
+    u = torch.rand(ei.shape[1], generator=g)
+    mf = TSPModel(_args("categorical", 50, H=H, L=Lyr), p, device=dev)
+    mu = TSPModel(_args("categorical", 50, H=H, L=Lyr), p, device=dev, fused=False)
+    a, la, _ = mf.categorical_denoise_step(pts, xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    b, lb, _ = mf.categorical_denoise_step(pts, xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    c, lc, _ = mu.categorical_denoise_step(pts, xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    assert torch.equal(a, b) and torch.equal(la, lb) and torch.isfinite(la).all() and set(a.unique().tolist()) <= {0.0, 1.0}
+    print(f"TSP-500 x16: fused vs unfused logits L_inf {(la - lc).abs().max().item():.3e}")
+    assert (la - lc).abs().max().item() < 5e-5
+    eis, off = [], 0
+    for gid in range(16):
+        n = int(np.random.default_rng(5000 + gid).integers(700, 801))
+        eis.append(er_mis_edge_index(n, 0.15, seed=1000 + gid) + off)
+        off += n
+    ei = torch.from_numpy(np.concatenate(eis, 1)).to(dev)
+    xt = (torch.randn(off, generator=g) > 0).float().to(dev)
+    u = torch.rand(off, generator=g)
+    mf = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev)
+    mu = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev, fused=False)
+    a, la, _ = mf.categorical_denoise_step(xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    b, lb, _ = mf.categorical_denoise_step(xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    c, lc, _ = mu.categorical_denoise_step(xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+    assert torch.equal(a, b) and torch.equal(la, lb) and torch.isfinite(la).all() and set(a.unique().tolist()) <= {0.0, 1.0}
+    print(f"MIS x16 ({off} nodes, {ei.shape[1]} edges): fused vs unfused logits L_inf {(la - lc).abs().max().item():.3e}")
+    assert (la - lc).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("task", ["tsp", "mis"])
+def test_free_running_trajectory_fused_h256(dev, task):
+    """test_free_running_trajectory on the DEFAULT path (H=256, fused kernel, fp16x3): GPU and oracle each feed their
+    own x_t for 12 steps with shared uniforms; the chains must stay bit-identical until a genuine tie."""
+    from difusco_amd import MISModel, TSPModel
+    H, Lyr, steps = 256, 4, 12
+    g = torch.Generator().manual_seed(111)
+    tab = O.CategoricalTables()
+    if task == "tsp":
+        p = O.init_params(H, Lyr, 2, seed=121)
+        pts, ei = O.tsp_instance(64, 10, seed=12)
+        pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
+        n_var = ei.shape[1]
+        m = TSPModel(_args("categorical", 10, H=H, L=Lyr), p, device=dev)
+        ref_step = lambda xt, t, tt, u: O.tsp_categorical_denoise_step(p, tab, pts, xt, t, ei, tt, uniform=u, return_aux=True)
+        gpu_step = lambda xt, t, tt, u: m.categorical_denoise_step(pts.to(dev), xt, np.array([t]), dev, ei.to(dev),
+                                                                   target_t=np.array([tt]), uniform=u, return_aux=True)
+    else:
+        p = O.init_params(H, Lyr, 2, seed=122)
+        ei = torch.from_numpy(O.er_mis_instance(150, 0.1, seed=13))
+        n_var = 150
+        m = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev)
+        ref_step = lambda xt, t, tt, u: O.mis_categorical_denoise_step(p, tab, xt, t, ei, tt, uniform=u, return_aux=True)
+        gpu_step = lambda xt, t, tt, u: m.categorical_denoise_step(xt, np.array([t]), dev, ei.to(dev), target_t=np.array([tt]),
+                                                                   uniform=u, return_aux=True)
+    x_ref = (torch.randn(n_var, generator=g) > 0).float()
+    x_gpu = x_ref.clone().to(dev)
+    agreed = 0
+    for i in range(steps):
+        t, tt = O.inference_schedule("cosine", 1000, 50, i)
+        u = torch.rand(n_var, generator=g)
+        x_ref, _, p_ref = ref_step(x_ref, t, tt, u)
+        x_gpu, _, p_gpu = gpu_step(x_gpu, t, tt, u)
+        assert (p_gpu.cpu().reshape(-1) - p_ref.reshape(-1)).abs().max().item() < TOL
+        if (u - p_ref.reshape(-1)).abs().min().item() < 1e-5:
+            break
+        assert torch.equal(x_gpu.cpu(), x_ref), f"trajectories diverged at step {i} without a tie"
+        agreed += 1
+    print(f"{task} (H=256, fused): {agreed} free-running steps bit-identical")
+    assert agreed >= 6

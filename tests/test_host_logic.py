@@ -329,3 +329,50 @@ def test_decode_entry_points_reject_bad_arguments_without_gpu():
     assert L.difusco_knn_graph(10, 11, p, 0, p, p, None, 0, None) < 0
     assert L.difusco_mis_decode(0, p, p, p, p, p, 1 << 20, None, None) < 0
     assert L.difusco_mis_decode_workspace_bytes(0, ctypes.byref(nbytes)) < 0
+
+
+# ------------------------------------------------------------------------------------------------
+# locality node order (graph.locality_node_order) and the graph cache key
+# ------------------------------------------------------------------------------------------------
+def test_locality_node_order_is_a_per_graph_permutation():
+    """Morton renumbering: a permutation that never mixes the graphs of a disjoint-union batch; the CSR built on the
+    renumbered graph describes the same edges, and ``perm`` still maps CSR slots to the caller's edge ids."""
+    import torch
+    from difusco_amd import graph, synthetic
+    n, k, G = 60, 7, 3
+    pts, ei = synthetic.tsp_batch(n, k, range(G))
+    g = graph.build_csr(ei, n * G, "cpu", points=pts)
+    assert g.node_order is not None
+    order = g.node_order.numpy()
+    assert np.array_equal(np.sort(order), np.arange(n * G))
+    assert np.array_equal(order.reshape(G, n) // n, np.repeat(np.arange(G)[:, None], n, axis=1))
+    inv = np.empty(n * G, dtype=np.int64)
+    inv[order] = np.arange(n * G)
+    e, perm = ei.numpy(), g.perm.numpy()
+    assert np.array_equal(inv[e[0][perm]], g.row.numpy()) and np.array_equal(inv[e[1][perm]], g.col.numpy())
+    assert np.array_equal(np.sort(perm), np.arange(e.shape[1]))
+    rp = g.rowptr.numpy()
+    assert np.all(np.diff(rp) == k) and np.all(np.diff(g.row.numpy()) >= 0)
+    # spatial neighbours are close in the new numbering: fewer distinct neighbour ids per window of edges
+    g0 = graph.build_csr(ei, n * G, "cpu")
+    win = lambda c: np.mean([len(np.unique(c[i:i + 64])) for i in range(0, c.shape[0], 64)])
+    assert win(g.col.numpy()) < win(g0.col.numpy())
+    # one connected blob (every node reaches across the id range): one block
+    ring = np.stack([np.arange(10), (np.arange(10) + 5) % 10])
+    assert graph._id_blocks(*graph.csr_from_coo_host(ring, 10)[:2], 10).max() == 0
+
+
+def test_prepare_graph_under_inference_mode():
+    """tensors created under torch.inference_mode() have no version counter (Lightning's default for
+    trainer.test); the graph cache key must not touch ``_version`` for them."""
+    import torch
+    from difusco_amd.models import COMetaModel
+    from difusco_amd import graph
+    m = COMetaModel.__new__(COMetaModel)
+    m._graph_cache, m.device, m.reorder_nodes = {}, "cpu", True
+    with torch.inference_mode():
+        ei = torch.tensor([[0, 0, 1, 1, 2, 2], [0, 1, 1, 2, 2, 0]])
+        pts = torch.rand(3, 2)
+        g1 = m.prepare_graph(ei, 3, points=pts)
+        g2 = m.prepare_graph(ei, 3, points=pts)
+    assert g1 is g2 and isinstance(g1, graph.CsrGraph) and g1.n_edges == 6

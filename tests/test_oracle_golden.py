@@ -177,3 +177,63 @@ def test_knn_graph_layout():
     assert (ei[1].reshape(64, 8)[:, 0] == np.arange(64)).all()  # self is the nearest neighbour
     d = np.linalg.norm(pts[ei[0]] - pts[ei[1]], axis=1).reshape(64, 8)
     assert (np.diff(d, axis=1) >= 0).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# production width (H=256, 3 layers): fixtures of tests/golden/make_golden_h256.py.  The weights come from
+# O.init_params(seed) and were loaded into the imported reference with strict=True (hash checked on load).
+# ------------------------------------------------------------------------------------------------
+def _check_cat_steps(z, n_steps, step):
+    for i in range(n_steps):
+        t, tt = (int(v) for v in z[f"cat{i}_t"])
+        u = torch.from_numpy(z[f"cat{i}_uniform"]) if f"cat{i}_uniform" in z.files else None
+        out, logits, prob = step(torch.from_numpy(z[f"cat{i}_xt"]), t, tt, u)
+        np.testing.assert_allclose(logits.numpy(), z[f"cat{i}_logits"], rtol=0, atol=TOL)
+        if u is not None:
+            ref_p = z[f"cat{i}_prob"]
+            np.testing.assert_allclose(prob.numpy().reshape(ref_p.shape), ref_p, rtol=0, atol=TOL)
+            safe = (np.abs(z[f"cat{i}_uniform"] - ref_p) > 1e-5).reshape(-1)
+            np.testing.assert_array_equal(out.numpy().reshape(-1)[safe], z[f"cat{i}_out"].reshape(-1)[safe])
+        else:
+            np.testing.assert_allclose(out.numpy(), z[f"cat{i}_out"], rtol=0, atol=TOL)
+
+
+def _check_gau_steps(z, n_steps, step):
+    for i in range(n_steps):
+        t, tt = (int(v) for v in z[f"gau{i}_t"])
+        out, pred = step(torch.from_numpy(z[f"gau{i}_xt"]), t, tt)
+        np.testing.assert_allclose(pred.numpy(), z[f"gau{i}_pred"].squeeze(1), rtol=0, atol=TOL)
+        np.testing.assert_allclose(out.numpy(), z[f"gau{i}_out"], rtol=0, atol=TOL)
+
+
+def test_h256_dense_tsp():
+    from conftest import load_h256_fixture
+    z, cat, gau = load_h256_fixture("tsp_dense_h256_l3_b1.npz")
+    assert "none executed" in str(z["provenance"])
+    pts = torch.from_numpy(z["points"])
+    tab, gt = O.CategoricalTables(), O.GaussianTables()
+    _check_cat_steps(z, 3, lambda xt, t, tt, u: O.tsp_categorical_denoise_step(cat, tab, pts, xt, t, None, tt, uniform=u,
+                                                                               return_aux=True))
+    _check_gau_steps(z, 2, lambda xt, t, tt: O.tsp_gaussian_denoise_step(gau, gt, pts, xt, t, None, tt, return_aux=True))
+
+
+@pytest.mark.parametrize("G", [1, 3])
+def test_h256_sparse_tsp(G):
+    from conftest import load_h256_fixture
+    z, cat, gau = load_h256_fixture(f"tsp_sparse_h256_l3_g{G}.npz")
+    assert "substitute aggregation" in str(z["provenance"])
+    pts, ei = torch.from_numpy(z["points"]), torch.from_numpy(z["edge_index"])
+    tab, gt = O.CategoricalTables(), O.GaussianTables()
+    _check_cat_steps(z, 4, lambda xt, t, tt, u: O.tsp_categorical_denoise_step(cat, tab, pts, xt, t, ei, tt, uniform=u,
+                                                                               return_aux=True))
+    _check_gau_steps(z, 2, lambda xt, t, tt: O.tsp_gaussian_denoise_step(gau, gt, pts, xt, t, ei, tt, return_aux=True))
+
+
+def test_h256_sparse_mis():
+    from conftest import load_h256_fixture
+    z, cat, gau = load_h256_fixture("mis_sparse_h256_l3.npz")
+    ei = torch.from_numpy(z["edge_index"])
+    tab, gt = O.CategoricalTables(), O.GaussianTables()
+    _check_cat_steps(z, 3, lambda xt, t, tt, u: O.mis_categorical_denoise_step(cat, tab, xt, t, ei, tt, uniform=u,
+                                                                               return_aux=True))
+    _check_gau_steps(z, 2, lambda xt, t, tt: O.mis_gaussian_denoise_step(gau, gt, xt, t, ei, tt, return_aux=True))
