@@ -346,7 +346,7 @@ __device__ __forceinline__ float categorical_step(float l0, float l1, float xt, 
   const float e0 = expf(l0 - m), e1 = expf(l1 - m);
   const float den = e0 + e1;
   const float p0 = e0 / den, p1 = e1 / den;
-  const int b = xt > 0.5f ? 1 : 0;
+  const int b = (int)xt >= 1 ? 1 : 0;      // x_t.long() (truncation, pl_meta_model.py:122); 0/1 inputs: the bit itself
   const float prob = __fadd_rn(__fmul_rn(pp.p[b], p0), __fmul_rn(pp.p[2 + b], p1));
   if (prob_out) *prob_out = prob;
   if (pp.p[4] != 0.0f) {

@@ -1,5 +1,5 @@
 """Heatmap -> tour on the GPU box: drop-in for ``merge_tours`` of the reference
-(``difusco/utils/tsp_utils.py:89-145``), sparse graphs only.
+(``difusco/utils/tsp_utils.py:89-145``), sparse (k-NN) and dense heatmaps.
 
 Same signature and return value as the reference function: ``(tours, merge_iterations)`` with one closed tour
 (list starting and ending at node 0) per parallel sample and the mean of the per-sample iteration counters.  The
@@ -25,15 +25,20 @@ def merge_tours(adj_mat, np_points, edge_index_np, sparse_graph=False, parallel_
                 return_completed=False):
     """``adj_mat``: [parallel_sampling * E] (or [parallel_sampling, E]) heat values in the edge order of
     ``edge_index_np`` ([2, E], the ONE graph's edges); ``np_points`` [N, 2].  numpy arrays or torch tensors."""
-    if not sparse_graph:
-        raise NotImplementedError("the MI355X decode path covers the sparse (k-NN) heatmap; dense TSP-50/100 heatmaps "
-                                  "are the reference's CPU plumbing case")
     device = torch.device(device)
     L = _lib.lib()
-    ei = _dev(edge_index_np, torch.int32, device)
     pts = _dev(np_points, torch.float32, device)
+    n = pts.shape[0]
+    if not sparse_graph:
+        # dense heatmaps [parallel_sampling, N, N] (tsp_utils.py:105-108: adj_mat[0] + adj_mat[0].T): the same greedy
+        # insertion over the complete directed edge list - entry (i, j) at i * N + j, so that the pair sums
+        # fl32(A_ij + A_ji), the doubled diagonal and the order of equal keys are those of the dense matrix
+        idx = torch.arange(n, dtype=torch.int32, device=device)
+        ei = torch.stack([idx.repeat_interleave(n), idx.repeat(n)])
+    else:
+        ei = _dev(edge_index_np, torch.int32, device)
     heat = _dev(adj_mat, torch.float32, device).reshape(parallel_sampling, -1)
-    n, E = pts.shape[0], ei.shape[1]
+    E = ei.shape[1]
     if heat.shape[1] != E:
         raise ValueError(f"adj_mat holds {heat.shape[1]} values per sample for {E} edges")
     nbytes = ctypes.c_size_t()

@@ -73,7 +73,15 @@ class COMetaModel:
                              f"{self.diffusion_type} diffusion needs {out_channels}")
         self.model = engine
         self.device = engine.device
-        self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 63 - 1)
+        if seed is None:
+            # default Philox key: torch's initial seed, made different per rank when torch.distributed runs (ranks of a
+            # sharded batch must not draw the same Bernoulli / normal streams).  An explicit ``seed=`` is used as given:
+            # callers that shard samples over ranks pass different seeds (bench.py: 1234 + rank).
+            seed = torch.initial_seed()
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                seed ^= (torch.distributed.get_rank() + 1) * 0x9E3779B97F4A7C15
+        self.seed = int(seed) & (2 ** 63 - 1)
+        self._binary_out = None     # (tensor, version) of the last Bernoulli-sampled output: known to be exactly {0,1}
         self._graph_cache = {}
         self.reorder_nodes = reorder_nodes      # TSP: Morton-order the nodes of every graph for L2 locality (graph.py)
         # optional: shard-summing callable for the head GroupNorm statistics (difusco_amd.dist.gn_allreduce); None =
@@ -116,6 +124,24 @@ class COMetaModel:
     def _next_offset(self) -> int:
         return self.model.calls
 
+    def _xt_is_binary(self, xt: torch.Tensor) -> bool:
+        """Is ``xt`` exactly {0,1}-valued?  The reference embeds whatever value arrives (``pl_tsp_model.py:127``:
+        ``xt.float()``) and truncates with ``.long()`` in the posterior (``pl_meta_model.py:122``); the two-row embedding
+        table and the table-input first layer are exact only for 0/1 inputs.  The sampling loop feeds our own Bernoulli
+        outputs back, which are known without looking (same storage, unmodified); anything else is checked on the
+        device (one small reduction + sync per call).  Values whose truncation is not 0/1 raise, like ``one_hot``."""
+        known = self._binary_out
+        if known is not None and known[0].data_ptr() == xt.data_ptr() and known[0].numel() == xt.numel() \
+                and not xt.is_inference() and known[1] == xt._version:
+            return True
+        if bool(((xt == 0) | (xt == 1)).all()):
+            return True
+        tr = xt.long()
+        if not bool(((tr == 0) | (tr == 1)).all()):
+            raise ValueError("categorical x_t must truncate to 0/1 (F.one_hot(xt.long(), num_classes=2), "
+                             "pl_meta_model.py:122-123)")
+        return False
+
     def _categorical(self, g, task, points, xt, t, target_t, uniform, return_aux):
         t, target_t = _as_int(t), _as_int(target_t)
         if target_t is None:
@@ -124,9 +150,10 @@ class COMetaModel:
         post[:4] = self.diffusion.posterior_constants(t, target_t)
         post[4] = 1.0 if target_t > 0 else 0.0                            # :139-142
         out, pred, prob = self.model.step(
-            g, task, _lib.CATEGORICAL, xt, float(t), post, points=points, xt_is_binary=True,
+            g, task, _lib.CATEGORICAL, xt, float(t), post, points=points, xt_is_binary=self._xt_is_binary(xt),
             rand=uniform if target_t > 0 else None, seed=self.seed, offset=self._next_offset(),
             want_pred=return_aux, want_prob=return_aux, gn_reduce=self.gn_reduce)
+        self._binary_out = (out, out._version) if (target_t > 0 and not out.is_inference()) else None
         return (out, pred, prob) if return_aux else out
 
     def _gaussian(self, g, task, points, xt, t, target_t, noise, return_aux):

@@ -74,15 +74,20 @@ def merge_dense(points, adj_mat):
 
 
 def merge_tours(adj_mat, np_points, edge_index_np, sparse_graph=True, parallel_sampling=1):
-    """tsp_utils.py:89-145 (sparse branch :106-115, tour walk :131-141).  Returns (tours, mean merge_iterations,
+    """tsp_utils.py:89-145 (dense branch :105-108, sparse branch :109-116, tour walk :131-141).  Returns (tours, mean merge_iterations,
     completed flags)."""
-    assert sparse_graph
-    parts = np.split(np.asarray(adj_mat, dtype=np.float32).reshape(-1), parallel_sampling, axis=0)
     n = np_points.shape[0]
+    if sparse_graph:
+        parts = np.split(np.asarray(adj_mat, dtype=np.float32).reshape(-1), parallel_sampling, axis=0)
+    else:                                                # :105-108: [parallel_sampling, N, N], adj_mat[0] + adj_mat[0].T
+        parts = [p[0] for p in np.split(np.asarray(adj_mat, dtype=np.float32).reshape(-1, n, n), parallel_sampling, axis=0)]
     tours, iters, done = [], [], []
     for part in parts:
-        a = np.zeros((n, n), dtype=np.float32)
-        np.add.at(a, (edge_index_np[0], edge_index_np[1]), part)
+        if sparse_graph:
+            a = np.zeros((n, n), dtype=np.float32)
+            np.add.at(a, (edge_index_np[0], edge_index_np[1]), part)
+        else:
+            a = part
         dense = a + a.T                                  # float32 add, as scipy's toarray() + toarray()
         real, it, ok = merge_dense(np_points, dense)
         tour = [0]

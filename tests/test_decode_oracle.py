@@ -63,6 +63,19 @@ def test_oracle_matches_reference_fixture(path):
         assert it_mean == float(z["merge_iterations"])
 
 
+DENSE = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tsp_densemerge_*.npz")))
+
+
+@pytest.mark.parametrize("path", DENSE, ids=[os.path.basename(p)[15:-4] for p in DENSE])
+def test_oracle_dense_merge_matches_reference_fixture(path):
+    """The dense branch of merge_tours (tsp_utils.py:105-108; BASELINE configs[0], TSP-50 dense heatmaps)."""
+    z = np.load(path)
+    par = int(z["parallel_sampling"])
+    assert len(DENSE) >= 3 and z["completed"].all()
+    tours, it, done = D.merge_tours(z["heat"], z["points"], None, sparse_graph=False, parallel_sampling=par)
+    assert all(done) and np.array_equal(np.asarray(tours), z["tours"]) and it == float(z["merge_iterations"])
+
+
 def test_fixtures_cover_both_regimes():
     flags = np.concatenate([np.load(p)["completed"] for p in GOLDEN])
     assert flags.any() and (~flags).any() and len(GOLDEN) >= 6

@@ -33,6 +33,20 @@ def test_merge_tours_matches_reference_fixture(dev, path):
         assert it_mean == float(z["merge_iterations"])
 
 
+def test_dense_merge_matches_reference_fixture(dev):
+    """The dense branch of merge_tours (tsp_utils.py:105-108): [parallel_sampling, N, N] heatmaps of the dense TSP-50
+    models (BASELINE configs[0]) against the reference's own output."""
+    from difusco_amd.decode import merge_tours
+    from test_decode_oracle import DENSE
+    assert len(DENSE) >= 3
+    for path in DENSE:
+        z = np.load(path)
+        par = int(z["parallel_sampling"])
+        tours, it, done = merge_tours(z["heat"], z["points"], None, sparse_graph=False, parallel_sampling=par, device=dev,
+                                      return_completed=True)
+        assert all(done) and np.array_equal(np.asarray(tours), z["tours"]) and it == float(z["merge_iterations"])
+
+
 def _heat(kind, pts, ei, rng):
     d = np.linalg.norm(pts[ei[0]] - pts[ei[1]], axis=1)
     if kind == "bits":
@@ -253,9 +267,49 @@ def test_solve_tsp_pipeline(dev):
     timings = {}
     tour, cost, costs, info = solve_tsp(m, pts, sparse_factor=10, parallel_sampling=3, two_opt_iterations=200, timings=timings)
     assert sorted(tour[:-1]) == list(range(80)) and tour[0] == tour[-1] == 0
-    assert abs(tour_length(pts, tour) - cost) < 1e-12 and cost == min(costs) and len(costs) == 3
+    pts32 = pts.astype(np.float32).astype(np.float64)      # the reference evaluates on the batch's float32 coordinates
+    assert abs(tour_length(pts32, tour) - cost) < 1e-12 and cost == min(costs) and len(costs) == 3
     assert all(c <= mc + 1e-9 for c, mc in zip(costs, info["merged_costs"]))
     assert set(timings) == {"knn", "sampling", "merge", "two_opt"}
+
+
+def test_solve_tsp_sequential_and_dense(dev):
+    """``sequential_sampling`` rounds (pl_tsp_model.py:185,238) and the dense TSP-50 flow of BASELINE configs[0]
+    (dense denoise steps -> dense merge -> 2-opt): valid tours, parallel x sequential costs, best = minimum."""
+    from difusco_amd import TSPModel
+    from difusco_amd.pipeline import solve_tsp, tour_length
+    from oracle import difusco_oracle as O
+    p = O.init_params(64, 2, 2, seed=0)
+    pts = np.random.default_rng(8).random((50, 2))
+    base = dict(diffusion_type="categorical", diffusion_schedule="linear", diffusion_steps=1000, n_layers=2, hidden_dim=64,
+                inference_trick="ddim", inference_diffusion_steps=8, inference_schedule="cosine")
+    for sparse_factor in (10, -1):
+        m = TSPModel(dict(base, sparse_factor=sparse_factor), p, device=dev, seed=3)
+        tour, cost, costs, info = solve_tsp(m, pts, sparse_factor=sparse_factor, parallel_sampling=2, two_opt_iterations=100,
+                                            sequential_sampling=3)
+        assert sorted(tour[:-1]) == list(range(50)) and tour[0] == tour[-1] == 0
+        assert len(costs) == 6 and cost == min(costs) and len(info["merged_costs"]) == 6
+        pts32 = pts.astype(np.float32).astype(np.float64)          # costs are evaluated on the float32 coordinates
+        assert abs(tour_length(pts32, tour) - cost) < 1e-12
+        assert all(c <= mc + 1e-9 for c, mc in zip(costs, info["merged_costs"]))
+        assert len(set(np.round(costs, 9))) > 1                     # the rounds drew different noise
+
+
+def test_solve_mis_sequential(dev):
+    from difusco_amd import MISModel
+    from difusco_amd.pipeline import solve_mis
+    from difusco_amd.synthetic import er_mis_edge_index
+    from oracle import difusco_oracle as O
+    n = 90
+    ei = er_mis_edge_index(n, 0.1, seed=4)
+    p = O.init_params(64, 2, 2, seed=1)
+    args = dict(diffusion_type="categorical", diffusion_schedule="linear", diffusion_steps=1000, sparse_factor=-1, n_layers=2,
+                hidden_dim=64, inference_trick="ddim", inference_diffusion_steps=6, inference_schedule="cosine")
+    m = MISModel(args, p, device=dev, seed=5)
+    sol, size, sizes = solve_mis(m, n, ei, parallel_sampling=2, sequential_sampling=3)
+    assert len(sizes) == 6 and size == max(sizes) == int(sol.sum())
+    a, b = ei[0], ei[1]
+    assert not np.any((sol[a] == 1) & (sol[b] == 1) & (a != b))
 
 
 def test_solve_mis_pipeline(dev):

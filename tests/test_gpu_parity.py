@@ -939,3 +939,49 @@ def test_free_running_trajectory_fused_h256(dev, task):
         agreed += 1
     print(f"{task} (H=256, fused): {agreed} free-running steps bit-identical")
     assert agreed >= 6
+
+
+@pytest.mark.parametrize("H,Lyr,prec", [(256, 3, "fp16x3"), (256, 3, "fp16x3/unfused"), (64, 2, "fp32")])
+def test_categorical_step_with_non_binary_xt(dev, H, Lyr, prec):
+    """a caller passing non-{0,1} x_t to the categorical step.  The reference embeds the raw float
+    (pl_tsp_model.py:127) and truncates with .long() in the posterior (pl_meta_model.py:122): 0.3 and 0.7 act as class 0,
+    1.2 as class 1.  The host detects the non-binary input and selects the general embedding path; values whose
+    truncation is not 0/1 raise (as one_hot does upstream)."""
+    from difusco_amd import MISModel, TSPModel
+    g = torch.Generator().manual_seed(5)
+    tab = O.CategoricalTables()
+    p = O.init_params(H, Lyr, 2, seed=55)
+    pts, ei = O.tsp_instance(50, 8, seed=9)
+    pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
+    vals = torch.tensor([0.0, 0.3, 0.7, 1.0, 1.2, 1.9])
+    xt = vals[torch.randint(0, 6, (ei.shape[1],), generator=g)]
+    u = torch.rand(ei.shape[1], generator=g)
+    m = TSPModel(_args("categorical", 8, H=H, L=Lyr), p, device=dev, **_prec(prec))
+    for (t, tt) in [(600, 560), (1, 0)]:
+        ref_out, ref_logits, ref_prob = O.tsp_categorical_denoise_step(p, tab, pts, xt, t, ei, tt, uniform=u, return_aux=True)
+        out, logits, prob = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev),
+                                                       target_t=np.array([tt]), uniform=u, return_aux=True)
+        e_log, e_prob = (logits.cpu() - ref_logits).abs().max().item(), (prob.cpu() - ref_prob.reshape(-1)).abs().max().item()
+        print(f"non-binary x_t, TSP {prec} H={H} t={t}: logits L_inf {e_log:.2e}, prob L_inf {e_prob:.2e}")
+        assert e_log < TOL and e_prob < TOL
+        if tt > 0:
+            safe = (u - ref_prob.reshape(-1)).abs() > 1e-4
+            assert torch.equal(out.cpu()[safe], ref_out[safe])
+    # the binary fast path and the general path agree on binary input (same model, x_t given as 0/1 floats vs ints)
+    xb = (xt >= 1).float()
+    a = m.categorical_denoise_step(pts.to(dev), xb.to(dev), np.array([600]), dev, ei.to(dev), target_t=np.array([560]), uniform=u)
+    b = m.categorical_denoise_step(pts.to(dev), xb.long().to(dev), np.array([600]), dev, ei.to(dev), target_t=np.array([560]), uniform=u)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        m.categorical_denoise_step(pts.to(dev), (xt + 2).to(dev), np.array([600]), dev, ei.to(dev), target_t=np.array([560]))
+    # MIS: node inputs always take the sinusoidal embedding of the raw value; the posterior truncates
+    eim = torch.from_numpy(O.er_mis_instance(70, 0.15, seed=6))
+    xm = vals[torch.randint(0, 6, (70,), generator=g)]
+    um = torch.rand(70, generator=g)
+    mm = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev, **_prec(prec))
+    ref_out, ref_logits, ref_prob = O.mis_categorical_denoise_step(p, tab, xm, 600, eim, 560, uniform=um, return_aux=True)
+    out, logits, prob = mm.categorical_denoise_step(xm.to(dev), np.array([600]), dev, eim.to(dev), target_t=np.array([560]),
+                                                    uniform=um, return_aux=True)
+    assert (logits.cpu() - ref_logits).abs().max().item() < TOL and (prob.cpu() - ref_prob.reshape(-1)).abs().max().item() < TOL
+    safe = (um - ref_prob.reshape(-1)).abs() > 1e-4
+    assert torch.equal(out.cpu()[safe], ref_out[safe])

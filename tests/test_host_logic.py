@@ -376,3 +376,25 @@ def test_prepare_graph_under_inference_mode():
         g1 = m.prepare_graph(ei, 3, points=pts)
         g2 = m.prepare_graph(ei, 3, points=pts)
     assert g1 is g2 and isinstance(g1, graph.CsrGraph) and g1.n_edges == 6
+
+
+def test_binary_input_detection_on_host():
+    """models.COMetaModel._xt_is_binary: {0,1} -> table path; other values whose truncation is 0/1 -> general path;
+    anything else raises like F.one_hot(xt.long(), num_classes=2) upstream (pl_meta_model.py:122-123)."""
+    import torch
+    from difusco_amd.models import COMetaModel
+    m = COMetaModel.__new__(COMetaModel)
+    m._binary_out = None
+    assert m._xt_is_binary(torch.tensor([0.0, 1.0, 1.0, 0.0])) is True
+    assert m._xt_is_binary(torch.tensor([0, 1, 1])) is True
+    assert m._xt_is_binary(torch.tensor([0.3, 0.7, 1.2, 0.0])) is False
+    assert m._xt_is_binary(torch.tensor([-0.5, 1.99])) is False
+    for bad in ([2.0, 0.0], [-1.0, 1.0], [0.0, float("nan")]):
+        with pytest.raises(ValueError):
+            m._xt_is_binary(torch.tensor(bad))
+    # a tensor remembered as our own Bernoulli output is trusted without a look - until it is modified in place
+    out = torch.tensor([0.0, 1.0])
+    m._binary_out = (out, out._version)
+    assert m._xt_is_binary(out) is True
+    out.add_(0.25)
+    assert m._xt_is_binary(out) is False
