@@ -118,6 +118,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //          compact set that stays in that XCD's 4 MiB L2;
   //   bit 1  the MFMAs of two weight blocks are issued alternately (two independent accumulator chains), so that no
   //          MFMA waits for the result of the one issued right before it.
+  //   bit 4  non-temporal accesses for the e stream (see kNt below).
+  // Production = 19 (bits 0, 1, 4): +5 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
+  // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
+  // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).
   // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
   // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
   constexpr int ablate = ABL;
@@ -148,6 +152,18 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // the scalar-base form; per-lane 64-bit pointers with large constant offsets cost a VGPR pair per address.
   float* const etile = e + (long long)tile * (32 * H);   // + slab * 512 + i * 256 + loff
   const unsigned loff = lane * 4;
+  // OPT bit 4: the e stream (read once, written once per layer: 1.6 GB per launch) moves with non-temporal accesses, so
+  // that it does not push the neighbour-table rows and the weight planes - both re-read by every workgroup of the
+  // XCD - out of the 4 MiB L2
+  constexpr bool kNt = (OPT & 16) != 0;
+  auto ld_e = [&](const float* p) -> v4f {
+    if constexpr (kNt) return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    else return *reinterpret_cast<const v4f*>(p);
+  };
+  auto st_e = [&](float* p, v4f v) {
+    if constexpr (kNt) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+    else *reinterpret_cast<v4f*>(p) = v;
+  };
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
   // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
   unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -170,8 +186,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   } else {
 #pragma unroll
     for (int d = 0; d < RING; ++d) {
-      er[d][0] = *reinterpret_cast<const v4f*>(etile + d * 512 + loff);
-      er[d][1] = *reinterpret_cast<const v4f*>(etile + (d * 512 + 256) + loff);
+      er[d][0] = ld_e(etile + d * 512 + loff);
+      er[d][1] = ld_e(etile + (d * 512 + 256) + loff);
     }
   }
 
@@ -241,18 +257,20 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // piece i of this wave (i < PP): LDS slot block PP*wave + i; its source lies i * 512 elements further in a GEMM 1
   // stage ([slab][256 rows][16]) and (i >> 1) * 4096 + (i & 1) * 512 in a GEMM 2 stage ([k slab][64 rows][16]) when a
   // wave covers more than one k slab (PP = 4), i * 512 otherwise
-#define FUSED_DMA_STAGE(t)                                                                                   \
+#define FUSED_DMA_PIECE(t, pl, i)                                                                            \
   {                                                                                                          \
     const int u_ = (t) - NS1;                                                                                \
     const int sbase = (t) < NS1 ? SPS * (t) * 4096 * 2 : ((KPS * (u_ % SPQ)) * 4096 + 64 * (u_ / SPQ) * 16) * 2; \
+    const int src_off = ((t) < NS1 || PP == 2) ? (i) * 512 : ((i) >> 1) * 4096 + ((i) & 1) * 512;           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                \
+        (t) < NS1 ? rs_c : rs_o,                                                                             \
+        (__attribute__((address_space(3))) void*)(wbuf + ((t) & 1) * BUF + (pl) * PLANE + (PP * wave + (i)) * 512), 16, \
+        ((t) < NS1 ? dvoff1 : dvoff2) * 2, sbase + (pl) * plane_bytes + src_off * 2, 0, 0);                  \
+  }
+#define FUSED_DMA_STAGE(t)                                                                                   \
+  {                                                                                                          \
     _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                         \
-      _Pragma("unroll") for (int i = 0; i < PP; ++i) {                                                       \
-        const int src_off = ((t) < NS1 || PP == 2) ? i * 512 : (i >> 1) * 4096 + (i & 1) * 512;             \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                            \
-            (t) < NS1 ? rs_c : rs_o,                                                                         \
-            (__attribute__((address_space(3))) void*)(wbuf + ((t) & 1) * BUF + pl * PLANE + (PP * wave + i) * 512), 16, \
-            ((t) < NS1 ? dvoff1 : dvoff2) * 2, sbase + pl * plane_bytes + src_off * 2, 0, 0);                \
-      }                                                                                                      \
+      _Pragma("unroll") for (int i = 0; i < PP; ++i) FUSED_DMA_PIECE(t, pl, i)                               \
   }
 #define FUSED_PIPE_BEGIN(t)                                         \
   if constexpr (kNoSync) {                                          \
@@ -309,6 +327,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   const float* nj = node4 + (long long)j * 4 * H;       // rows U | V | A | B
   const float* ni = node4 + (long long)i_node * 4 * H;
 
+  v16f acc1[8];
   if constexpr (kDma) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage 0 has landed
   } else {
@@ -318,7 +337,6 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   __syncthreads();
 
   FUSED_STAMP(1)
-  v16f acc1[8];
   if constexpr (L0) {      // C e_in of this lane's features, from the row that belongs to its input row
     const int ce_row = l0_row + (P_CE0 - P_TAB0) * H;
 #pragma unroll
@@ -352,8 +370,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
         c0 = er[ks % RING][0];
         c1 = er[ks % RING][1];
         if (!kNoE && ks + RING < 16) {
-          er[ks % RING][0] = *reinterpret_cast<const v4f*>(etile + (ks + RING) * 512 + loff);
-          er[ks % RING][1] = *reinterpret_cast<const v4f*>(etile + ((ks + RING) * 512 + 256) + loff);
+          er[ks % RING][0] = ld_e(etile + (ks + RING) * 512 + loff);
+          er[ks % RING][1] = ld_e(etile + ((ks + RING) * 512 + 256) + loff);
         }
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -585,7 +603,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             if constexpr (L0) ein[nbp][g] = *reinterpret_cast<const v4f*>(prm + l0_row + 64 * qt + 32 * nbp + 8 * g + 4 * hh);
-            else ein[nbp][g] = *reinterpret_cast<const v4f*>(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff);
+            else ein[nbp][g] = ld_e(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff);
           }
       }
       const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
@@ -656,7 +674,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           v4f v;
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
-          *reinterpret_cast<v4f*>(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff) = v;
+          st_e(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff, v);
           if constexpr (GNP) {
             gs[nbp * 4 + g] = (v[0] + v[1]) + (v[2] + v[3]);
             gq[nbp * 4 + g] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -687,6 +705,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #undef FUSED_PIPE_BEGIN
 #undef FUSED_PIPE_END
 #undef FUSED_DMA_STAGE
+#undef FUSED_DMA_PIECE
 }
 
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
@@ -718,10 +737,8 @@ hipError_t launch_fused_t(float* e, const float* node4, const int* row, const in
 template <typename T, bool L0, bool GNP, int TAIL, typename... A>
 hipError_t launch_fused_opt(A... args) {
   switch (g_fused_opt) {
-    case 1: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 1>(args...);
-    case 2: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 2>(args...);
-    case 3: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 3>(args...);
-    default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 0>(args...);
+    case 0: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 0>(args...);
+    default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 19>(args...);
   }
 }
 

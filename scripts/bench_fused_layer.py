@@ -71,15 +71,18 @@ L.difusco_debug_set(0, 0)
 L.difusco_debug_set(7, 0)
 # the scheduling options must not change a single bit
 outs = []
-for opt in (0, 1, 2, 3):
+OPTS = (0, 19)
+for opt in OPTS:
     L.difusco_debug_set(7, opt)
     e, h = e0.clone(), h0.clone()
     run(e, h)
     torch.cuda.synchronize()
     outs.append((e, h))
 L.difusco_debug_set(7, 0)
-for opt in (1, 2, 3):
-    print(f"opt {opt} vs opt 0: bit-identical e {torch.equal(outs[0][0], outs[opt][0])}, h {torch.equal(outs[0][1], outs[opt][1])}")
+for idx, opt in enumerate(OPTS):
+    if idx:
+        print(f"opt {opt} vs opt 0: bit-identical e {torch.equal(outs[0][0], outs[idx][0])}, h {torch.equal(outs[0][1], outs[idx][1])}; "
+              f"max |diff| e {(outs[0][0] - outs[idx][0]).abs().max().item():.2e} h {(outs[0][1] - outs[idx][1]).abs().max().item():.2e}")
 if len(sys.argv) > 3 and sys.argv[3] == 'nostamp':
     sys.exit(0)
 # phase timestamps (s_memtime, 100 MHz-class constant clock or shader clock - reported as raw ticks and as shares)

@@ -11,7 +11,10 @@ import os
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+# key of the profiled run in profiles/<round>/pmc_traffic.json: "<workload>:<edges on rank 0>:<variant>" (bench.py looks its
+# own run up under exactly this key and reports traffic = null when the run was never profiled)
+run_key = sys.argv[2] if len(sys.argv) > 2 else "tsp1000:800000:fused-fp16x3"
 root = "gpurun_out"
 
 
@@ -26,7 +29,7 @@ def short(name):
 
 
 stats = find(f"prof_stats_{tag}", "*kernel_stats.csv")
-print(f"# rocprofv3 --kernel-trace --stats  (bench.py --steps 5 --warmup 2, TSP-1000 K=100, 8 graphs, H=256, L=12)")
+print(f"# rocprofv3 --kernel-trace --stats  (bench.py --steps 5 --warmup 2 {os.environ.get('PROF_BENCH_ARGS', '')}; run key {run_key})")
 if stats:
     rows = list(csv.DictReader(open(stats)))
     print(f"{'kernel':92s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
@@ -67,4 +70,10 @@ for counter, d in (("FETCH_SIZE", f"prof_fetch_{tag}"), ("WRITE_SIZE", f"prof_wr
 import json
 for t in traffic.values():
     t.pop("_n", None)
-json.dump(traffic, open(os.path.join(root, f"pmc_traffic_{tag}.json"), "w"), indent=1)
+path = os.path.join(root, f"pmc_traffic_{tag}.json")
+try:
+    table = json.load(open(path))
+except (OSError, ValueError):
+    table = {}
+table[run_key] = traffic
+json.dump(table, open(path, "w"), indent=1)
