@@ -19,6 +19,32 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.p
            os.path.join(os.path.dirname(PKG), "include", "difusco_hip.h")]
 
 
+TORCH_LIB_PATH = os.path.join(LIB_DIR, "libdifusco_torch.so")
+TORCH_SRC = os.path.join(CSRC, "torch_ops.cpp")
+
+
+def build_torch_ops(force: bool = False, verbose: bool = False) -> str:
+    """The PyTorch custom-op shim (csrc/torch_ops.cpp: ``torch.ops.difusco.*`` over the C ABI), compiled with the host
+    compiler against this interpreter's torch and linked to libdifusco_hip.so next to it.  In-tree, like the HIP library."""
+    deps = [TORCH_SRC, HEADERS[-1], LIB_PATH]
+    if not force and os.path.exists(TORCH_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(TORCH_LIB_PATH) for d in deps):
+        return TORCH_LIB_PATH
+    import torch
+    from torch.utils import cpp_extension
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-w", TORCH_SRC, "-o", TORCH_LIB_PATH]
+           + [f"-I{p}" for p in cpp_extension.include_paths()] + ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__=1",
+              "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}", f"-L{tlib}", "-ltorch",
+              "-ltorch_cpu", "-lc10", "-ltorch_hip", "-lc10_hip", f"-L{LIB_DIR}", "-ldifusco_hip", "-Wl,-rpath,$ORIGIN",
+              f"-Wl,-rpath,{tlib}"])
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libdifusco_torch.so failed:\n" + res.stdout + res.stderr)
+    return TORCH_LIB_PATH
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -61,3 +87,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_torch_ops(force="--force" in sys.argv, verbose=True))

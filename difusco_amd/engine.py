@@ -17,7 +17,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class DenoiseEngine:
     def __init__(self, state_dict, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
-                 fused: bool = True):
+                 fused: bool = True, backend: str = "ctypes"):
         """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
         ``blob``: an already packed blob (e.g. received by RCCL broadcast) instead of packing here."""
         self.device = torch.device(device)
@@ -32,6 +32,12 @@ class DenoiseEngine:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
         self.precision = precision
         self.fused = fused          # fused edge-layer kernel (H == 256, precision bf16x3 / fp16x3)
+        if backend not in ("ctypes", "torch"):
+            raise ValueError("backend must be 'ctypes' (C ABI through ctypes) or 'torch' (torch.ops.difusco custom ops)")
+        self.backend = backend
+        if backend == "torch":
+            from . import torch_ops
+            self._ops = torch_ops.load()
         self._ws = None
         self.calls = 0
 
@@ -79,6 +85,9 @@ class DenoiseEngine:
         pred = torch.empty((rows, 2) if C == 2 else (rows,), dtype=torch.float32, device=dev) if want_pred else None
         prob = torch.empty(rows, dtype=torch.float32, device=dev) if (want_prob and C == 2) else None
         ws = self._workspace(g)
+        if self.backend == "torch":
+            return self._step_torch_op(g, task, diffusion, xt, t, post, points, xt_is_binary, rand, seed, offset,
+                                       want_pred, want_prob, gn_reduce, ws)
 
         a = _lib.StepArgs()
         a.struct_size = ctypes.sizeof(_lib.StepArgs)
@@ -119,3 +128,30 @@ class DenoiseEngine:
                 _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
         self.calls += 1
         return xt_out, pred, prob
+
+    def _step_torch_op(self, g, task, diffusion, xt, t, post, points, xt_is_binary, rand, seed, offset, want_pred,
+                       want_prob, gn_reduce, ws):
+        """The same step through ``torch.ops.difusco.denoise_step_{categorical,gaussian}`` (csrc/torch_ops.cpp)."""
+        op = self._ops.denoise_step_categorical if diffusion == _lib.CATEGORICAL else self._ops.denoise_step_gaussian
+        cfg = [self.hidden, self.n_layers, self.out_channels, task, _lib.PRECISIONS[self.precision], 0 if self.fused else 1,
+               1 if xt_is_binary else 0, 0]
+        seg = g.seg_ptr if g.n_segments > 1 else None
+        post = [float(v) for v in post]
+        seed, offset = int(seed) & (2 ** 63 - 1), int(offset) & (2 ** 63 - 1)
+
+        def call(phase, sums):
+            cfg[7] = phase
+            return op(self.blob, g.rowptr, g.col, g.perm, g.row, seg, points, xt, float(t), post, rand, seed, offset, ws, cfg,
+                      want_pred, want_prob, sums)
+        if gn_reduce is None:
+            out = call(0, None)
+        else:
+            if g.n_segments != 1:
+                raise ValueError("global GroupNorm statistics need one statistic segment per call")
+            sums = torch.zeros(65, dtype=torch.float64, device=self.device)
+            call(1, sums)
+            gn_reduce(sums)
+            out = call(2, sums)
+        self.calls += 1
+        xt_out, pred, prob = out
+        return xt_out, (pred if want_pred else None), (prob if (want_prob and self.out_channels == 2) else None)

@@ -1,30 +1,59 @@
-"""On-disk heatmap formats of the reference, host side only:
+"""On-disk heatmap formats of the reference.
 
 * ``save_numpy_heatmap``  - the ``.npy`` pair written by ``TSPModel.run_save_numpy_heatmap``
-  (``difusco/pl_tsp_model.py:255-267``): ``{split}-heatmap-{idx}.npy`` and ``{split}-points-{idx}.npy`` under
+  (``difusco/pl_tsp_model.py:258-267``): ``{split}-heatmap-{idx}.npy`` and ``{split}-points-{idx}.npy`` under
   ``<dir>/numpy_heatmap``.
-* ``mcts_heatmap_text``   - the text file the C++ MCTS tool reads (``tsp_mcts/convert_numpy_to_txt.py:18-72``,
-  reader ``tsp_mcts/.../TSP_IO.h:461-492``): first line N, then N rows of ``%.6f`` after adding the distance prior,
-  keeping the top ``expected_valid_prob`` share of the entries plus the 3 largest of every row, symmetrising and
-  row-normalising.  The input is a DENSE N x N heatmap, as in the reference; ``densify`` turns the sparse (E-entry)
-  heatmap of the k-NN models into one.
+* ``write_mcts_heatmap`` / ``mcts_heatmap_rows`` - the text file the C++ MCTS tool reads
+  (``tsp_mcts/convert_numpy_to_txt.py:18-72``): first line N, then N rows of N ``%.6f`` numbers.
 
-Plain numpy with the reference's dtypes and operation order, so the text is identical character for character."""
+What the converter computes, per instance (all in the dtype of its inputs, float32 for the model's heatmaps):
+
+    v[i][j] = heat[i][j] + 0.01 * (1 - |p_i - p_j|)                  every ordered pair (the distance prior is dense)
+    keep    = { v > T } U { the 3 largest entries of every row },     T = the K-th largest positive v, K = int(N*N*prob)
+    m       = (v on keep, 0 elsewhere), + 0.01 on its non-zeros;  out = (m + m^T) / rowsum(m + m^T)
+
+The reference materialises five N x N arrays for this (800 MB each in float64 at N = 10^4).  Here the
+heatmap stays SPARSE - the E entries of the k-NN models' output - and nothing N x N is ever allocated:
+
+The distance prior makes every one of the N^2 entries a candidate (at N = 10^4 with the default 2 % the threshold lies
+among entries that carry the prior alone), and the output is N^2 numbers by definition - so the work is O(N^2) either
+way.  What need not be O(N^2) is the memory: ``v`` is recomputed for ``block_rows`` rows at a time with the converter's
+own numpy expression, and three sweeps over the block rows do everything:
+
+1. histogram of the positive values by the 16 high bits of their float32 pattern + the row top-3;
+2. the one histogram bucket that contains T is collected and sorted: T exactly, no N^2 sort;
+3. per block: the masked block, the masked TRANSPOSE block (the distance is symmetric, the transposed heat entries and
+   the transposed top-3 memberships are scattered into it), their sum, numpy's own row sums, the division - the same
+   operations on the same values as the reference's whole-matrix statements - then vectorised ``%.6f`` formatting
+   (including the reference's ``-0.000000`` where both orientations carry a negative prior) streamed to the file.
+
+Memory: O(E + block_rows * N) (about 2 M entries per buffer by default).
+
+The output is identical, character for character, to the reference converter's on the committed fixtures
+(``tests/golden/mcts_text_*.npz``, produced by importing ``tsp_mcts/convert_numpy_to_txt.py``)."""
 import os
+from typing import Iterator, Optional, Tuple
 
 import numpy as np
 
 
 def densify(heat, edge_index, n_nodes: int) -> np.ndarray:
-    """[E] heat values on the directed edges of ``edge_index`` -> dense [N,N] float32 (entries off the graph are 0)."""
+    """[E] heat values on the directed edges of ``edge_index`` -> dense [N,N] float32 (entries off the graph are 0).
+    Small instances / tests only - the MCTS text path below never needs it."""
     a = np.zeros((n_nodes, n_nodes), dtype=np.float32)
     ei = np.asarray(edge_index)
     a[ei[0], ei[1]] = np.asarray(heat, dtype=np.float32)
     return a
 
 
+def sparsify(dense: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Dense [N,N] heatmap -> (heat [E], edge_index [2,E]) of its non-zero entries, row-major order."""
+    r, c = np.nonzero(dense)
+    return dense[r, c], np.stack([r, c]).astype(np.int64)
+
+
 def save_numpy_heatmap(adj_mat, np_points, save_dir: str, real_batch_idx: int, split: str = "test"):
-    """pl_tsp_model.py:255-267.  Returns the two paths."""
+    """pl_tsp_model.py:258-267.  Returns the two paths."""
     heatmap_path = os.path.join(save_dir, "numpy_heatmap")
     os.makedirs(heatmap_path, exist_ok=True)
     hp = os.path.join(heatmap_path, f"{split}-heatmap-{real_batch_idx}.npy")
@@ -34,42 +63,177 @@ def save_numpy_heatmap(adj_mat, np_points, save_dir: str, real_batch_idx: int, s
     return hp, pp
 
 
-def mcts_normalise(adj_matrix: np.ndarray, points: np.ndarray, num_nodes: int, expected_valid_prob: float = 0.02) -> np.ndarray:
-    """convert_numpy_to_txt.py:21-47 on one instance."""
-    dists = np.linalg.norm(points[:, None, :] - points[None, :, :], axis=-1)
-    adj_matrix = adj_matrix + 0.01 * (1.0 - dists)
-    adj_matrix[adj_matrix == np.inf] = 0.0
-    expected_valid_value_num = int(num_nodes * num_nodes * expected_valid_prob)
-    valid_values = adj_matrix[(adj_matrix > 0.0)]
-    valid_values = np.sort(valid_values)
-    valid_value_threshold = valid_values[-expected_valid_value_num]
-    top3_nodes_per_node = np.argsort(adj_matrix, axis=1)[:, -3:]
-    valid_mask = adj_matrix > valid_value_threshold
-    top3_mask = np.zeros_like(adj_matrix, dtype=bool)
-    top3_mask[np.arange(num_nodes)[:, None], top3_nodes_per_node] = True
-    valid_mask = valid_mask | top3_mask
-    adj_matrix = adj_matrix * valid_mask
-    adj_matrix[adj_matrix != 0.0] += 1e-2
-    adj_matrix = adj_matrix + adj_matrix.T
-    adj_matrix = adj_matrix / adj_matrix.sum(axis=1, keepdims=True)
-    return adj_matrix
+# ------------------------------------------------------------------------------------------------
+# the converter's arithmetic on gathered operands (the only place the reference's formula appears)
+# ------------------------------------------------------------------------------------------------
+def _prior_values(heat, pts, rows, cols):
+    """v = heat + 0.01 * (1 - dist) for the entries (rows[k], cols[k]); same dtype promotion as the reference's
+    ``adj_matrix + 0.01 * (1.0 - dists)`` (convert_numpy_to_txt.py:21-22), inf -> 0 (:24)."""
+    d = np.linalg.norm(pts[rows] - pts[cols], axis=-1)
+    v = heat + 0.01 * (1.0 - d)
+    v[v == np.inf] = 0.0
+    return v
+
+
+def _block_values(heat_rows, pts, lo, hi):
+    """The dense values of rows lo..hi-1: [hi-lo, N]; ``heat_rows`` holds the scattered heat of those rows."""
+    d = np.linalg.norm(pts[lo:hi, None, :] - pts[None, :, :], axis=-1)
+    v = heat_rows + 0.01 * (1.0 - d)
+    v[v == np.inf] = 0.0
+    return v
+
+
+class _SparseHeat:
+    """The E heat entries in CSR order (sorted by row, then column) with duplicate-free (row, col) pairs."""
+
+    def __init__(self, heat, edge_index, n):
+        ei = np.asarray(edge_index, dtype=np.int64)
+        heat = np.asarray(heat)
+        if heat.dtype not in (np.float32, np.float64):
+            heat = heat.astype(np.float32)
+        order = np.lexsort((ei[1], ei[0]))
+        self.row, self.col, self.heat = ei[0][order], ei[1][order], heat.reshape(-1)[order]
+        key = self.row * n + self.col
+        if key.size > 1 and np.any(key[1:] == key[:-1]):
+            raise ValueError("duplicate (row, col) entries in the sparse heatmap")
+        self.n = n
+        self.rowptr = np.searchsorted(self.row, np.arange(n + 1))
+
+    def block(self, lo, hi, dtype):
+        a = np.zeros((hi - lo, self.n), dtype=dtype)
+        s, e = self.rowptr[lo], self.rowptr[hi]
+        a[self.row[s:e] - lo, self.col[s:e]] = self.heat[s:e]
+        return a
+
+
+def _threshold_and_top3(sp: _SparseHeat, pts, k: int, block_rows: int, dtype):
+    """(T, top3): T = the k-th largest positive entry of the dense value matrix (``np.sort(valid_values)[-k]``,
+    convert_numpy_to_txt.py:27-29), top3 [N,3] = the last three columns of every row's argsort (:33).  Two block-row
+    sweeps: the first histograms the positive values by the 16 high bits of their float32 pattern (positive floats
+    order like their bit patterns) and takes the row top-3, the second collects the one bucket that holds T."""
+    n = sp.n
+
+    def blocks():
+        for lo in range(0, n, block_rows):
+            hi = min(n, lo + block_rows)
+            yield lo, hi, _block_values(sp.block(lo, hi, dtype), pts, lo, hi)
+    top3 = np.empty((n, 3), dtype=np.int64)
+    if dtype != np.float32:                       # float64 heatmaps: keep every positive value (small inputs only)
+        parts = []
+        for lo, hi, v in blocks():
+            top3[lo:hi] = np.argsort(v, axis=1)[:, -3:]
+            parts.append(v[v > 0.0])
+        return np.sort(np.concatenate(parts))[-k], top3
+    hist = np.zeros(1 << 16, dtype=np.int64)
+    for lo, hi, v in blocks():
+        top3[lo:hi] = np.argsort(v, axis=1)[:, -3:]
+        hist += np.bincount(v[v > 0.0].view(np.uint32) >> 16, minlength=1 << 16)
+    if k > hist.sum():
+        raise IndexError("fewer positive entries than expected_valid_value_num")     # the reference fails here as well
+    above = np.cumsum(hist[::-1])[::-1]                                   # positive entries in buckets >= b
+    bucket = int(np.nonzero(above >= k)[0].max())
+    rank = k - (int(above[bucket + 1]) if bucket + 1 < (1 << 16) else 0)  # T is the rank-th largest inside the bucket
+    cand = []
+    for lo, hi, v in blocks():
+        pos = v[v > 0.0]
+        cand.append(pos[(pos.view(np.uint32) >> 16) == bucket])
+    return np.sort(np.concatenate(cand))[-rank], top3
+
+
+def mcts_heatmap_rows(heat, edge_index, points, num_nodes: int, expected_valid_prob: float = 0.02,
+                      block_rows: Optional[int] = None) -> Iterator[np.ndarray]:
+    """Yields the normalised rows ([N] arrays, dtype of the inputs) of the MCTS heatmap for the SPARSE heatmap
+    ``heat`` [E] on the directed edges ``edge_index`` [2,E]; ``points`` [N,2].  See the module docstring."""
+    n = int(num_nodes)
+    pts = np.asarray(points)
+    heat = np.asarray(heat)
+    dtype = np.result_type(heat.dtype if heat.dtype.kind == "f" else np.float32, pts.dtype)
+    pts = pts.astype(dtype, copy=False)
+    if block_rows is None:
+        block_rows = max(1, min(n, (1 << 21) // max(n, 1)))                 # ~2 M entries per block-row buffer
+    sp = _SparseHeat(heat.astype(dtype, copy=False), edge_index, n)
+    spt = _SparseHeat(sp.heat, np.stack([sp.col, sp.row]), n)               # the transposed entries: heat[j][i] at (i, j)
+    k = int(n * n * expected_valid_prob)                                    # convert_numpy_to_txt.py:26
+    if k < 1:
+        raise IndexError("expected_valid_value_num is 0 (the reference would take valid_values[-0])")
+    thr, top3 = _threshold_and_top3(sp, pts, k, block_rows, dtype)
+    t3_rows = np.repeat(np.arange(n, dtype=np.int64), 3)
+    t3_cols = top3.reshape(-1)
+    by_col = np.argsort(t3_cols, kind="stable")                             # top-3 membership, indexed by column
+    t3c_sorted, t3r_sorted = t3_cols[by_col], t3_rows[by_col]
+    bump = np.asarray(1e-2, dtype=dtype)
+
+    def masked(v, keep):
+        m = v * keep                                                        # :44  (a negative value times False is -0.0)
+        m[m != 0.0] += bump                                                 # :45
+        return m
+
+    for lo in range(0, n, block_rows):
+        hi = min(n, lo + block_rows)
+        v = _block_values(sp.block(lo, hi, dtype), pts, lo, hi)             # v[i][j], i in the block
+        keep = v > thr                                                      # :35
+        keep[np.arange(lo, hi)[:, None] - lo, top3[lo:hi]] = True           # :41-43
+        vt = _block_values(spt.block(lo, hi, dtype), pts, lo, hi)           # v[j][i] at [i][j]: the distance is symmetric
+        keept = vt > thr
+        s, e = np.searchsorted(t3c_sorted, lo), np.searchsorted(t3c_sorted, hi)
+        keept[t3c_sorted[s:e] - lo, t3r_sorted[s:e]] = True                 # (j, i) with i among the top 3 of row j
+        out = masked(v, keep) + masked(vt, keept)                           # :46
+        out = out / out.sum(axis=1, keepdims=True)                          # :47, numpy's own row sum
+        for r in range(hi - lo):
+            yield out[r]
+
+
+def _format_rows(rows: Iterator[np.ndarray], n: int) -> Iterator[bytes]:
+    """Rows -> text lines of ``%.6f`` numbers.  Vectorised: every slot is [sign or nothing][8 characters][space]; zeros
+    (and the reference's ``-0.000000`` where both orientations of a pair carry a negative prior) come from a template,
+    only the non-zeros are formatted."""
+    slot = np.frombuffer(b"\x000.000000 ", dtype=np.uint8)
+    minus = ord("-")
+    for row in rows:
+        tok = np.tile(slot, (n, 1))
+        tok[np.signbit(row), 0] = minus
+        wide = False
+        for j in np.nonzero(row)[0]:
+            txt = f"{abs(float(row[j])):.6f}".encode()
+            if len(txt) != 8:                     # >= 10: not produced by a normalised row; fall back to plain formatting
+                wide = True
+                break
+            tok[j, 1:9] = np.frombuffer(txt, dtype=np.uint8)
+        if wide:
+            yield (" ".join(f"{x:.6f}" for x in row) + "\n").encode()
+            continue
+        flat = tok.reshape(-1)
+        yield flat[flat != 0].tobytes()[:-1] + b"\n"
 
 
 def mcts_heatmap_text(adj_matrix: np.ndarray, points: np.ndarray, num_nodes: int, expected_valid_prob: float = 0.02) -> str:
-    """convert_numpy_to_txt.py:57-71: the normalised matrix as text."""
-    m = mcts_normalise(np.array(adj_matrix), np.asarray(points), num_nodes, expected_valid_prob)
-    out = [f"{num_nodes}\n"]
-    for row in range(num_nodes):
-        out.append(" ".join([f"{x:.6f}" for x in m[row]]) + "\n")
-    return "".join(out)
+    """The converter's text for a DENSE [N,N] heatmap (small instances, the reference's input form): its non-zero
+    entries go through the sparse path above."""
+    dense = np.asarray(adj_matrix)
+    heat, ei = sparsify(dense)
+    rows = mcts_heatmap_rows(heat.astype(dense.dtype if dense.dtype.kind == "f" else np.float32), ei, points, num_nodes,
+                             expected_valid_prob)
+    return f"{num_nodes}\n" + b"".join(_format_rows(rows, num_nodes)).decode()
 
 
-def write_mcts_heatmap(adj_matrix, points, num_nodes: int, output_dir: str, index: int, heatmap_prefix: str = "heatmap",
-                       expected_valid_prob: float = 0.02) -> str:
-    """File name and directory layout of convert_numpy_to_txt.py:60-66."""
+def write_mcts_heatmap(heat, points, num_nodes: int, output_dir: str, index: int, heatmap_prefix: str = "heatmap",
+                       expected_valid_prob: float = 0.02, edge_index=None, block_rows: int = 256) -> str:
+    """File name and directory layout of convert_numpy_to_txt.py:60-66; rows are streamed to the file.  ``heat`` is
+    either a dense [N,N] array (``edge_index`` None) or the sparse [E] heatmap on ``edge_index`` [2,E] - numpy arrays or
+    torch tensors (the sampler's output is moved to the host: E floats)."""
+    def host(x):
+        return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+    heat, points = host(heat), host(points)
+    if edge_index is None:
+        heat, edge_index = sparsify(heat)
+    else:
+        edge_index = host(edge_index)
     folder = f"{output_dir}/{heatmap_prefix}/tsp{num_nodes}"
     os.makedirs(folder, exist_ok=True)
     path = f"{folder}/heatmaptsp{num_nodes}_{index}.txt"
-    with open(path, "w") as f:
-        f.write(mcts_heatmap_text(adj_matrix, points, num_nodes, expected_valid_prob))
+    rows = mcts_heatmap_rows(heat, edge_index, points, num_nodes, expected_valid_prob, block_rows)
+    with open(path, "wb") as f:
+        f.write(f"{num_nodes}\n".encode())
+        for line in _format_rows(rows, num_nodes):
+            f.write(line)
     return path

@@ -44,7 +44,7 @@ class COMetaModel:
 
     def __init__(self, param_args=None, state_dict=None, node_feature_only=False, device="cuda:0",
                  seed: Optional[int] = None, engine: Optional[DenoiseEngine] = None, precision: str = "fp16x3",
-                 fused: bool = True, gn_reduce=None, reorder_nodes: bool = True):
+                 fused: bool = True, gn_reduce=None, reorder_nodes: bool = True, backend: str = "ctypes"):
         args = dict(_DEFAULTS)
         if param_args is not None:
             args.update(vars(param_args) if not isinstance(param_args, dict) else param_args)
@@ -67,7 +67,7 @@ class COMetaModel:
         if engine is None:
             if state_dict is None:
                 raise ValueError("state_dict (reference GNNEncoder weights) or engine required")
-            engine = DenoiseEngine(state_dict, device=device, precision=precision, fused=fused)
+            engine = DenoiseEngine(state_dict, device=device, precision=precision, fused=fused, backend=backend)
         if engine.out_channels != out_channels:
             raise ValueError(f"weights have {engine.out_channels} output channels, "
                              f"{self.diffusion_type} diffusion needs {out_channels}")

@@ -39,3 +39,33 @@ for name, n, prob, seed in [("n30", 30, 0.1, 1), ("n64", 64, 0.02, 2)]:
                         expected_valid_prob=np.float64(prob), text=np.frombuffer(text.encode(), dtype=np.uint8),
                         provenance="reference: tsp_mcts/convert_numpy_to_txt.main (fire placeholder, np.bool alias)")
     print(name, len(text), "chars")
+
+# ---- a k-NN-sparse heatmap at N = 1000 (K = 50): the input form of the sparse models.  The reference needs the dense
+# matrix, the product path (difusco_amd.formats) works from the E entries; the fixture stores the entries and the text.
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from difusco_amd.synthetic import tsp_instance  # noqa: E402
+n, K, prob = 1000, 50, 0.02
+pts, ei = tsp_instance(n, K, seed=77)
+rng = np.random.default_rng(9)
+d = np.linalg.norm(pts[ei[0]] - pts[ei[1]], axis=1)
+heat_e = (np.clip(np.exp(-d / (0.35 * d.mean())) * rng.random(ei.shape[1]) ** 2, 0, 1).astype(np.float32) + np.float32(1e-6))
+dense = np.zeros((n, n), dtype=np.float32)
+dense[ei[0], ei[1]] = heat_e
+tmp = tempfile.mkdtemp(prefix="difusco_fmt_")
+os.makedirs(os.path.join(tmp, "numpy_heatmap"))
+np.save(os.path.join(tmp, "numpy_heatmap", "test-heatmap-0.npy"), dense)
+np.save(os.path.join(tmp, "numpy_heatmap", "test-points-0.npy"), pts)
+had = hasattr(np, "bool")
+if not had:
+    np.bool = bool
+try:
+    ref.main(tmp, os.path.join(tmp, "out"), num_nodes=n, num_files=1, expected_valid_prob=prob)
+finally:
+    if not had:
+        del np.bool
+text = open(os.path.join(tmp, "out", "heatmap", f"tsp{n}", f"heatmaptsp{n}_0.txt")).read()
+np.savez_compressed(os.path.join(HERE, "mcts_sparse_text_n1000_k50.npz"), heat=heat_e, edge_index=ei.astype(np.int32), points=pts,
+                    num_nodes=np.int64(n), expected_valid_prob=np.float64(prob),
+                    text=np.frombuffer(text.encode(), dtype=np.uint8),
+                    provenance="reference: tsp_mcts/convert_numpy_to_txt.main on the densified k-NN heatmap (fire placeholder, np.bool alias)")
+print("n1000_k50", len(text), "chars", os.path.getsize(os.path.join(HERE, "mcts_sparse_text_n1000_k50.npz")), "bytes")

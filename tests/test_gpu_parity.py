@@ -985,3 +985,35 @@ def test_categorical_step_with_non_binary_xt(dev, H, Lyr, prec):
     assert (logits.cpu() - ref_logits).abs().max().item() < TOL and (prob.cpu() - ref_prob.reshape(-1)).abs().max().item() < TOL
     safe = (um - ref_prob.reshape(-1)).abs() > 1e-4
     assert torch.equal(out.cpu()[safe], ref_out[safe])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_torch_custom_ops_equal_ctypes_path(dev, fused):
+    """torch.ops.difusco.denoise_step_* (csrc/torch_ops.cpp) against the ctypes binding of the same C ABI: bitwise equal
+    outputs for TSP categorical / Gaussian and MIS, and for the two-phase global-statistics step."""
+    from difusco_amd import MISModel, TSPModel
+    H, Lyr, N, K, G = 256, 3, 80, 10, 2
+    p, pg = O.init_params(H, Lyr, 2, seed=71), O.init_params(H, Lyr, 1, seed=72)
+    pts1, ei1 = O.tsp_instance(N, K, seed=8)
+    pts = torch.from_numpy(np.tile(pts1, (G, 1))).to(dev)
+    ei = O.duplicate_edge_index(torch.from_numpy(ei1), N, G).to(dev)
+    g = torch.Generator().manual_seed(6)
+    xt = (torch.randn(ei.shape[1], generator=g) > 0).float().to(dev)
+    u = torch.rand(ei.shape[1], generator=g)
+    t, tt = np.array([400]), np.array([370])
+    res = {}
+    for backend in ("ctypes", "torch"):
+        m = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev, fused=fused, backend=backend, seed=9)
+        res[backend, "cat"] = m.categorical_denoise_step(pts, xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+        res[backend, "philox"] = (m.categorical_denoise_step(pts, xt, t, dev, ei, target_t=tt),)     # on-device draw
+        m2 = TSPModel(_args("categorical", K, H=H, L=Lyr), p, device=dev, fused=fused, backend=backend, gn_reduce=lambda s: s.mul_(1.0))
+        res[backend, "two_phase"] = m2.categorical_denoise_step(pts, xt, t, dev, ei, target_t=tt, uniform=u, return_aux=True)
+        mg = TSPModel(_args("gaussian", K, H=H, L=Lyr), pg, device=dev, fused=fused, backend=backend)
+        res[backend, "gau"] = mg.gaussian_denoise_step(pts, torch.randn(ei.shape[1], generator=torch.Generator().manual_seed(1)).to(dev),
+                                                       t, dev, ei, target_t=tt, return_aux=True)
+        eim = torch.from_numpy(O.er_mis_instance(100, 0.1, seed=2)).to(dev)
+        mm = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev, fused=fused, backend=backend)
+        res[backend, "mis"] = mm.categorical_denoise_step(xt[:100], t, dev, eim, target_t=tt, uniform=u[:100], return_aux=True)
+    for key in ("cat", "philox", "two_phase", "gau", "mis"):
+        for a, b in zip(res["ctypes", key], res["torch", key]):
+            assert torch.equal(a, b), key

@@ -398,3 +398,56 @@ def test_binary_input_detection_on_host():
     assert m._xt_is_binary(out) is True
     out.add_(0.25)
     assert m._xt_is_binary(out) is False
+
+
+# ------------------------------------------------------------------------------------------------
+# torch.library registration of the step (csrc/torch_ops.cpp; north_star "PyTorch-ROCm custom ops")
+# ------------------------------------------------------------------------------------------------
+def test_torch_ops_registered_and_host_ops_match_the_c_abi():
+    import torch
+    from difusco_amd import _lib, graph, torch_ops
+    ops = torch_ops.load()
+    assert ops.abi_version() == _lib.ABI_VERSION
+    for name in ("prepare_graph", "weights_layout", "workspace_bytes", "denoise_step_categorical", "denoise_step_gaussian"):
+        assert hasattr(ops, name), name
+    schema = str(ops.denoise_step_categorical.default._schema)
+    assert schema.startswith("difusco::denoise_step_categorical(Tensor weights, Tensor rowptr, Tensor col, Tensor? perm")
+    assert "-> (Tensor, Tensor, Tensor)" in schema
+    # host ops against the ctypes binding of the same C functions
+    ei = O_er = torch.from_numpy(__import__("oracle.difusco_oracle", fromlist=["x"]).er_mis_instance(40, 0.2, seed=3))
+    rowptr, col, row, perm, ident = ops.prepare_graph(ei, 40)
+    r2, c2, w2, p2, i2 = graph.csr_from_coo_host(ei.numpy(), 40)
+    assert np.array_equal(rowptr.numpy(), r2) and np.array_equal(col.numpy(), c2) and np.array_equal(row.numpy(), w2)
+    assert np.array_equal(perm.numpy(), p2) and ident == i2
+    off, tot = _lib.weights_layout(256, 12, 2)
+    lay = ops.weights_layout(256, 12, 2)
+    assert lay[:-1].tolist() == off and int(lay[-1]) == tot
+    assert ops.workspace_bytes(256, 12, 1000, 100000, 1) == _lib.lib().difusco_workspace_bytes(256, 12, 1000, 100000, 1)
+    with pytest.raises(RuntimeError):          # CPU tensors are refused by the step ops (no CPU kernel is registered)
+        z = torch.zeros(4)
+        ops.denoise_step_categorical(z, z.int(), z.int(), None, None, None, None, z, 1.0, [0.0] * 5, None, 0, 0, z, [64, 2, 2, 0, 3, 0, 1, 0],
+                                     False, False, None)
+
+
+def test_mcts_text_from_sparse_heatmap_matches_reference(golden_dir, tmp_path):
+    """(f)-4 from the E-entry heatmap of a k-NN model (N=1000, K=50): the streamed text equals the reference
+    converter's output on the densified matrix, for several block sizes (nothing N x N is allocated)."""
+    from difusco_amd import formats
+    z = np.load(os.path.join(golden_dir, "mcts_sparse_text_n1000_k50.npz"))
+    n, prob = int(z["num_nodes"]), float(z["expected_valid_prob"])
+    ref_text = bytes(z["text"]).decode()
+    assert ref_text.count("-0.000000") > 0          # the reference's signed zeros (both orientations negative) are covered
+    path = formats.write_mcts_heatmap(z["heat"], z["points"], n, str(tmp_path), 0, expected_valid_prob=prob,
+                                      edge_index=z["edge_index"])
+    assert path.endswith(f"heatmap/tsp{n}/heatmaptsp{n}_0.txt") and open(path).read() == ref_text
+    rows_a = list(formats.mcts_heatmap_rows(z["heat"], z["edge_index"], z["points"], n, prob, block_rows=37))
+    rows_b = list(formats.mcts_heatmap_rows(z["heat"], z["edge_index"], z["points"], n, prob, block_rows=1000))
+    assert all(np.array_equal(a, b) and a.dtype == np.float32 for a, b in zip(rows_a, rows_b)) and len(rows_a) == n
+    # shuffled entry order, torch tensors
+    import torch
+    perm = np.random.default_rng(0).permutation(z["heat"].shape[0])
+    path2 = formats.write_mcts_heatmap(torch.from_numpy(z["heat"][perm]), torch.from_numpy(z["points"]), n, str(tmp_path), 1,
+                                       expected_valid_prob=prob, edge_index=torch.from_numpy(z["edge_index"][:, perm].astype(np.int64)))
+    assert open(path2).read() == ref_text
+    with pytest.raises(ValueError):
+        list(formats.mcts_heatmap_rows(np.ones(2, np.float32), np.array([[0, 0], [1, 1]]), z["points"][:4], 4, 0.5))
