@@ -195,12 +195,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
-    if not torch.cuda.is_available():
+    # Test hook (tests/test_dist_cpu.py): BENCH_PLUMBING_DRY_RUN=1 walks the multi-rank plumbing of this file on CPU tensors
+    # over gloo - rendezvous, rank-0 packing + blob broadcast, graph sharding, the optional statistics all-reduce, the
+    # barriers and the max-over-ranks timing - with the denoise step replaced by a stand-in that runs NO kernel.  Its JSON
+    # line is marked "dry_run" and is not a measurement.
+    dry = os.environ.get("BENCH_PLUMBING_DRY_RUN") == "1"
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback path)")
     if os.environ.get("BENCH_SINGLE_DEVICE") == "1":     # test hook: several ranks on one GPU (with BENCH_BACKEND=gloo)
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if dry:
+        device = torch.device("cpu")
+        os.environ["BENCH_BACKEND"] = "gloo"
+        args.no_profile, args.no_exact_fp32, args.cpu_steps = True, True, 0
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
@@ -227,7 +237,13 @@ def main():
 
     # frozen weights: rank 0 creates, RCCL broadcast of the packed blob over xGMI
     params = random_state_dict(H, LAYERS, 1 if gaussian else 2, seed=20240926) if rank == 0 or world == 1 else None
-    if world > 1:
+    if dry:
+        from difusco_amd.dist import broadcast_weights
+        if world > 1:
+            (h_, l_, c_), blob = broadcast_weights(params, device, src=0)
+            assert (h_, l_, c_) == (H, LAYERS, 1 if gaussian else 2) and blob.numel() > 0 and bool(torch.isfinite(blob).all())
+        engine = None
+    elif world > 1:
         engine = engine_from_broadcast(params, device, src=0, precision=args.precision, fused=not args.no_fusion)
     else:
         engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion)
@@ -235,8 +251,22 @@ def main():
                  inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn if not mis else -1,
                  n_layers=LAYERS, hidden_dim=H, inference_trick="ddim")
     gn_reduce = gn_allreduce() if (args.gn_stats == "global" and world > 1) else None
-    model = (MISModel if mis else TSPModel)(margs, engine=engine, seed=1234 + rank, gn_reduce=gn_reduce,
-                                            reorder_nodes=not args.no_node_reorder)
+    if dry:
+        class _PlumbingModel:      # no kernel: hands x_t back, and exercises the statistics all-reduce when asked for
+            def _step(self, xt):
+                if gn_reduce is not None:
+                    sums = torch.full((65,), float(rank + 1), dtype=torch.float64)
+                    gn_reduce(sums)
+                    assert float(sums[0]) == world * (world + 1) / 2, "all-reduce of the GroupNorm sums did not add up"
+                return xt
+
+            def categorical_denoise_step(self, *a, **k):
+                return self._step(a[1] if not mis else a[0])
+            gaussian_denoise_step = categorical_denoise_step
+        model = _PlumbingModel()
+    else:
+        model = (MISModel if mis else TSPModel)(margs, engine=engine, seed=1234 + rank, gn_reduce=gn_reduce,
+                                                reorder_nodes=not args.no_node_reorder)
 
     # this rank's shard of the global batch (weak scaling: graphs_per_gpu fixed)
     G_total = args.graphs_per_gpu * world
@@ -253,7 +283,11 @@ def main():
         N_local = n_off
         xt = (torch.randn(N_local, generator=gen) > 0).float().to(device)
     else:
-        points, edge_index = tsp_batch_gpu(args.nodes, args.knn, range(lo, hi), device)   # k-NN graphs built on the GPU
+        if dry:
+            from difusco_amd.synthetic import tsp_batch
+            points, edge_index = tsp_batch(args.nodes, args.knn, range(lo, hi), device)
+        else:
+            points, edge_index = tsp_batch_gpu(args.nodes, args.knn, range(lo, hi), device)   # k-NN graphs built on the GPU
         N_local = points.shape[0]
         xt = torch.randn(edge_index.shape[1], generator=gen)
         xt = (xt if gaussian else (xt > 0).float()).to(device)
@@ -272,10 +306,12 @@ def main():
         return mdl.categorical_denoise_step(points, xt, t1, device, edge_index, target_t=t2)
 
     def fence():
-        torch.cuda.synchronize(device)
+        if not dry:
+            torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if not dry:
+            torch.cuda.synchronize(device)
 
     for i in range(args.warmup):
         xt = one_step(i, xt)
@@ -304,12 +340,12 @@ def main():
     if rank == 0:
         value = G_total * args.steps / dt
         out = {
-            "metric": "denoising steps/sec (graphs x steps / s), " + (
+            "metric": ("PLUMBING DRY RUN, NO KERNEL RAN - " if dry else "") + "denoising steps/sec (graphs x steps / s), " + (
                 "MIS ER-[700,800] sparse categorical" if mis else
                 f"TSP-{args.nodes} k-NN sparse {wl['diffusion']}"),
             "value": value, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", **({"dry_run": True} if dry else {}),
             "config": {"workload": (f"MIS Erdos-Renyi n~U[700,800] p=0.15 (+reverse edges, +self loops) sparse categorical"
                                     if mis else f"TSP-{args.nodes} k-NN K={args.knn} sparse {wl['diffusion']}") +
                                    f", cosine 50-step schedule, {args.graphs_per_gpu} graphs per GPU "

@@ -82,3 +82,29 @@ def test_broadcast_and_shard_two_processes():
     assert ret[0][3] == (0, 3) and ret[1][3] == (3, 5)
     assert ret[0][4] == (60, 2) and ret[1][4] == (40, 2)
     assert ret[0][6] and ret[1][6]            # gn_allreduce summed the 65 doubles over both ranks
+
+
+@pytest.mark.parametrize("gn_stats", ["per_shard_call", "global"])
+def test_bench_py_multi_rank_plumbing_dry_run(gn_stats):
+    """bench.py's world > 1 branch end to end, the way the driver launches it (``python -m torch.distributed.run
+    --nproc-per-node 2 ... bench.py --gpus 2``), on CPU tensors over gloo with BENCH_PLUMBING_DRY_RUN=1: rendezvous,
+    rank-0 packs and the blob is broadcast, graphs are sharded, the optional 65-double all-reduce runs every step, the
+    barriers and the max-over-ranks timing complete, rank 0 prints ONE JSON line marked ``dry_run`` (no kernel ran)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_PLUMBING_DRY_RUN="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--nodes", "40", "--knn", "6", "--graphs-per-gpu", "3", "--gn-stats", gn_stats]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["metric"].startswith("PLUMBING DRY RUN")
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 6 and out["config"]["graphs_per_gpu"] == 3 and out["config"]["gn_stats"] == gn_stats
+    assert out["config"]["nodes_rank0"] == 120 and out["config"]["edges_rank0"] == 720       # rank 0 holds 3 of the 6 graphs
+    assert out["value"] > 0 and abs(out["value"] - 6 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
