@@ -57,23 +57,28 @@ def pmc_traffic_bytes(kernel_name, workload, n_edges, variant):
     return None
 
 
-def physical_cores():
+def oracle_threads():
+    """torch threads for the CPU-oracle leg.  Measured on the GPU box's host (2 x EPYC 9575F, 128 physical cores,
+    profiles/r02/cpu_threads_scan.txt, one TSP-1000 step): 16 threads 4.8 s, 32 threads 4.2 s, 64 threads 5.7 s,
+    128 threads 10.5 s - the E-row GEMMs of one graph do not scale past one CCD group, so 32 (capped by the physical
+    core count) is what the leg uses and reports as `cores`."""
     try:
         import psutil
-        return int(psutil.cpu_count(logical=False) or os.cpu_count() or 1)
+        phys = int(psutil.cpu_count(logical=False) or os.cpu_count() or 1)
     except Exception:
-        return int(os.cpu_count() or 1)
+        phys = int(os.cpu_count() or 1)
+    return max(1, min(32, phys))
 
 
 def cpu_baseline(wl, steps, params, gpu_model, device):
     """The CPU oracle (port of the reference op sequence, incl. V applied on E gathered rows) on a bounded
-    sample: ONE graph of the same workload, 1 warm-up + `steps` timed denoise steps, torch threads = physical cores
-    (the default, one thread per SMT sibling, oversubscribes the GEMMs).  The first timed step is also run on the GPU
+    sample: ONE graph of the same workload, 1 warm-up + `steps` timed denoise steps, torch threads = oracle_threads()
+    (the default, one thread per SMT sibling, oversubscribes the GEMMs 2.5x).  The first timed step is also run on the GPU
     (same graph, same x_t, same injected uniforms, default engine) and the network outputs are compared:
     "parity_linf".  This leg is the only place where bench.py touches oracle/."""
     from oracle import difusco_oracle as O
     from difusco_amd.synthetic import er_mis_edge_index, tsp_instance
-    cores = physical_cores()
+    cores = oracle_threads()
     prev_threads = torch.get_num_threads()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
@@ -136,7 +141,7 @@ def cpu_baseline(wl, steps, params, gpu_model, device):
     out = {"value": steps / dt, "unit": "graph-steps/s", "cores": cores, "kind": "port",
            "sample": f"{what} H={H} L={LAYERS} fp32 {wl['diffusion']}, 1 warm-up + {steps} timed steps "
                      f"of the CPU oracle ({dt:.1f} s, incl. one GPU step for the parity check), "
-                     f"torch.set_num_threads({cores}) = physical cores"}
+                     f"torch.set_num_threads({cores}) (fastest of 16/32/64/128 on this host class, profiles/r02/cpu_threads_scan.txt)"}
     out.update(parity)
     return out
 
@@ -176,7 +181,7 @@ def main():
                     help="head GroupNorm statistics: over each rank's own call (default, no collective in the loop) or "
                          "over the whole sharded batch (one all-reduce of 65 doubles per step)")
     ap.add_argument("--fused-opt", type=int, default=None, help="A/B: scheduling options of the fused kernel "
-                    "(difusco_debug_set key 7; bit 0 XCD-contiguous tile ranges, bit 1 alternating MFMA chains)")
+                    "(difusco_debug_set key 7: 0 = all off, default = production set)")
     ap.add_argument("--no-node-reorder", action="store_true", help="A/B: keep the caller's node numbering (no Morton order)")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32 (v_mfma_f32_32x32x2_f32) sub-record")
     ap.add_argument("--precision", default="fp16x3", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/difusco_hip.h"
@@ -125,6 +126,9 @@ Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk)
 // (bench.py needs the average duration of the dominant kernel measured on the launch stream inside
 // the timed region; the launches happen inside difusco_denoise_step, so the brackets live here.)
 enum { PROF_LINEAR_EDGE = 0, PROF_LINEAR_NODE, PROF_GATE, PROF_HEAD, PROF_EMBED, PROF_NCAT };
+// (process-wide, like the HIP events it owns; every access goes through g_prof_mu, so that two engines driven from two
+// host threads cannot corrupt it - their brackets simply share the category totals)
+std::mutex g_prof_mu;
 struct Profiler {
   bool on = false;
   bool dominant_only = false;   // bracket category 0 (the E-row / fused edge-layer launches) only
@@ -138,6 +142,7 @@ struct ProfScope {
   bool active;
   size_t slot;
   ProfScope(int category, hipStream_t s) : st(s), active(false), slot(0) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof.on || (g_prof.dominant_only && category != PROF_LINEAR_EDGE) || g_prof.used * 2 + 2 > g_prof.ev.size()) return;
     slot = g_prof.used++;
     g_prof.cat[slot] = category;
@@ -509,6 +514,7 @@ int difusco_debug_set(int key, int value) {
 }
 
 int difusco_profile_enable(int on, int max_launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (on) {
     if (max_launches < 1) max_launches = 1;
     while (g_prof.ev.size() < (size_t)max_launches * 2) {
@@ -526,6 +532,7 @@ int difusco_profile_enable(int on, int max_launches) {
 
 int difusco_profile_collect(double* ms, int64_t* launches, int n_categories) {
   if (!ms || !launches || n_categories < PROF_NCAT) return fail(DIFUSCO_EINVAL, "need %d categories", PROF_NCAT);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int c = 0; c < n_categories; ++c) { ms[c] = 0.0; launches[c] = 0; }
   for (size_t i = 0; i < g_prof.used; ++i) {
     HIP_TRY(hipEventSynchronize(g_prof.ev[2 * i + 1]));

@@ -61,7 +61,7 @@ int g_fused_lds_pad = 0;  // profiling only (difusco_debug_set key 6)
 int g_fused_gn_fold = 1;  // 1: last-layer variants - TSP: GroupNorm partial sums + no node update; MIS: no edge
                           //    output (difusco_debug_set key 4)
 int g_fused_l0_fold = 1;  // 1: the first layer reads its edge input from the 2-row table (difusco_debug_set key 3)
-int g_fused_opt = 19;     // OPT bits of the kernel (difusco_debug_set key 7: 0 or 19): results are identical for both
+int g_fused_opt = FUSED_OPT;   // difusco_debug_set key 7: 0 = all scheduling options off (A/B), anything else = production
 unsigned long long* g_fused_dbg = nullptr;   // profiling: device buffer for phase timestamps, [n_tiles][8]
 
 hipError_t launch_fused_fp16(int kind, FUSED_KIND_PARAMS) { return launch_fused_kind<FFp16>(kind, FUSED_KIND_ARGS); }

@@ -14,11 +14,11 @@ hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS) {
     case 8: return launch_fused_t<FFp16, 8, FUSED_NW>(ABL_ARGS);      // no GEMM 2
     case 15: return launch_fused_t<FFp16, 15, FUSED_NW>(ABL_ARGS);    // GEMM 1 + weight streaming only
     case 16: return launch_fused_t<FFp16, 16, FUSED_NW>(ABL_ARGS);    // production code + phase timestamps
-    case 17: return launch_fused_t<FFp16, 15, FUSED_NW, false, false, 0, 19>(ABL_ARGS);   // 15 with the production options
-    case 18: return launch_fused_t<FFp16, 16, FUSED_NW, false, false, 0, 19>(ABL_ARGS);   // 16 (phase stamps), production options
-    case 22: return launch_fused_t<FFp16, 16 + 32768, FUSED_NW, false, false, 0, 19>(ABL_ARGS);   // stamps, no e stream
-    case 23: return launch_fused_t<FFp16, 16 + 16384, FUSED_NW, false, false, 0, 19>(ABL_ARGS);   // stamps, no stage refills / barriers
-    case 24: return launch_fused_t<FFp16, 16 + 1, FUSED_NW, false, false, 0, 19>(ABL_ARGS);       // stamps, no gathers
+    case 17: return launch_fused_t<FFp16, 15, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);   // 15 with the production options
+    case 18: return launch_fused_t<FFp16, 16, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);   // 16 (phase stamps), production options
+    case 22: return launch_fused_t<FFp16, 16 + 32768, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);   // stamps, no e stream
+    case 23: return launch_fused_t<FFp16, 16 + 16384, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);   // stamps, no stage refills / barriers
+    case 24: return launch_fused_t<FFp16, 16 + 1, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);       // stamps, no gathers
     default: return hipErrorInvalidValue;
   }
 #undef ABL_ARGS

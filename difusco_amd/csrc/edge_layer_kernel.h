@@ -119,9 +119,11 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //   bit 1  the MFMAs of two weight blocks are issued alternately (two independent accumulator chains), so that no
   //          MFMA waits for the result of the one issued right before it.
   //   bit 4  non-temporal accesses for the e stream (see kNt below).
-  // Production = 19 (bits 0, 1, 4): +5 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
+  //   bit 5  two stages of cover for the e stream (kDeepE below);  bit 6  LayerNorm reductions as four partial sums (kPart).
+  // Production = 115 (bits 0, 1, 4, 5, 6): +6 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
-  // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).
+  // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5 do not change a result bit; bit 6
+  // changes the summation order of the LayerNorm statistics (fp32 rounding, ~1e-6 on e).
   // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
   // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
   constexpr int ablate = ABL;
@@ -357,9 +359,15 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   const int a_off = wslot(l31, hh);   // entry = 32 nb + l31 : (entry >> 3) & 1 == (l31 >> 3) & 1
 
   // ================================ GEMM 1 ==========================================================
+  // OPT bit 5: two stages of cover for the e stream.  The slab of stage t is split BEFORE this stage's weight requests
+  // are issued and the ring slot is refilled AFTER them, so the two youngest requests of a stage are its e loads; the
+  // stage then ends with vmcnt(2) instead of vmcnt(0): the weight pieces have landed (requests complete in order), the
+  // e loads stay in flight across the barrier and are waited for at the end of the NEXT stage.
+  constexpr bool kDeepE = (OPT & 32) != 0;
+  static_assert(!kDeepE || (kDma && SPS == 1 && RING == 2), "OPT bit 5 is written for the 16 KiB LDS-DMA stages");
 #pragma unroll
   for (int t = 0; t < (L0 ? 0 : NS1); ++t) {
-    FUSED_PIPE_BEGIN(t)
+    if constexpr (!kDeepE) { FUSED_PIPE_BEGIN(t) }
     // B operands of the slab(s) of this stage
     frag xh[SPS], xl[SPS];
 #pragma unroll
@@ -369,13 +377,22 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       {
         c0 = er[ks % RING][0];
         c1 = er[ks % RING][1];
-        if (!kNoE && ks + RING < 16) {
+        if (!kDeepE && !kNoE && ks + RING < 16) {
           er[ks % RING][0] = ld_e(etile + (ks + RING) * 512 + loff);
           er[ks % RING][1] = ld_e(etile + ((ks + RING) * 512 + 256) + loff);
         }
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       split8<T>(xs, xh[sub], xl[sub]);
+    }
+    if constexpr (kDeepE) {
+      __builtin_amdgcn_sched_barrier(0);
+      FUSED_PIPE_BEGIN(t)
+      if (!kNoE && t + RING < 16) {
+        er[t % RING][0] = ld_e(etile + (t + RING) * 512 + loff);
+        er[t % RING][1] = ld_e(etile + ((t + RING) * 512 + 256) + loff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // 8 SPS weight blocks (bi = sub * 8 + nb), A fragments read from LDS two blocks ahead of their MFMAs
     const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
@@ -421,7 +438,16 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       }
     }
 #undef FUSED_FRAG1
-    FUSED_PIPE_END(t)
+    if constexpr (kDeepE) {
+      if (!kNoE && t + RING < 16) {
+        __builtin_amdgcn_s_waitcnt(0x0F72);      // vmcnt(2): everything but this stage's two e loads
+        __syncthreads();
+      } else {
+        FUSED_PIPE_END(t)
+      }
+    } else {
+      FUSED_PIPE_END(t)
+    }
     if (t == 0) { FUSED_STAMP(2) }
     if (t == NS1 / 2 - 1) { FUSED_STAMP(3) }
   }
@@ -430,7 +456,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // ================================ epilogue 1 =======================================================
   // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3.
   // Neighbour-table rows are gathered one batch (= 2 quads) ahead of their use.
-  float s1 = 0.0f;
+  // OPT bit 6: the four LayerNorm reductions (sum, centred sum of squares, twice) run as FOUR interleaved partial sums per
+  // lane instead of one 128-term serial chain each; same terms, different summation order (fp32 rounding only)
+  constexpr bool kPart = (OPT & 64) != 0;
+  float s1 = 0.0f, s1p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   // segment structure of the tile: bit k of bnd = edge k starts a new centre node (wave uniform)
   const int i_prev = __shfl_up(i_node, 1, 64);
   const unsigned bnd = (unsigned)__ballot(l31 > 0 && i_node != i_prev);
@@ -475,7 +504,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
         const float ce = acc1[nb][4 * g + q] + bc[q];
         const float ev = (ah[q] + bh[q]) + ce;
         acc1[nb][4 * g + q] = ev;
-        s1 += ev;
+        if constexpr (kPart) s1p[q] += ev; else s1 += ev;
         if constexpr (TAIL != 1) m[q] = valid ? fast_sigmoid(ev) * vh[q] : 0.0f;   // (select: pad lanes may hold anything)
       }
       if constexpr (TAIL != 1) *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
@@ -515,18 +544,20 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
   constexpr float inv_h = 1.0f / 256.0f;
   constexpr bool skip_math = (ablate & 4) != 0;
+  if constexpr (kPart) s1 = (s1p[0] + s1p[1]) + (s1p[2] + s1p[3]);
   const float mean1 = skip_math ? 0.0f : (s1 + __shfl_xor(s1, 32, 64)) * inv_h;
-  float q1 = 0.0f;
+  float q1 = 0.0f, q1p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float d = acc1[nb][r] - mean1;
       acc1[nb][r] = d;
-      q1 += d * d;
+      if constexpr (kPart) q1p[r & 3] += d * d; else q1 += d * d;
     }
+  if constexpr (kPart) q1 = (q1p[0] + q1p[1]) + (q1p[2] + q1p[3]);
   const float rstd1 = __builtin_amdgcn_rsqf((q1 + __shfl_xor(q1, 32, 64)) * inv_h + 1e-5f);
-  float s2 = 0.0f;
+  float s2 = 0.0f, s2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr (!skip_math) {
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
@@ -541,20 +572,22 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           float y = acc1[nb][4 * g + q] * rstd1 * ge[q] + be[q];
           y = (y > 0.0f ? y : 0.0f) + tb[q];
           acc1[nb][4 * g + q] = y;
-          s2 += y;
+          if constexpr (kPart) s2p[q] += y; else s2 += y;
         }
       }
   }
+  if constexpr (kPart) s2 = (s2p[0] + s2p[1]) + (s2p[2] + s2p[3]);
   const float mean2 = (s2 + __shfl_xor(s2, 32, 64)) * inv_h;
-  float q2s = 0.0f;
+  float q2s = 0.0f, q2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float d = acc1[nb][r] - mean2;
       acc1[nb][r] = d;
-      q2s += d * d;
+      if constexpr (kPart) q2p[r & 3] += d * d; else q2s += d * d;
     }
+  if constexpr (kPart) q2s = (q2p[0] + q2p[1]) + (q2p[2] + q2p[3]);
   const float rstd2 = __builtin_amdgcn_rsqf((q2s + __shfl_xor(q2s, 32, 64)) * inv_h + 1e-5f);
 
   // activation -> 16-bit planes, kept in registers as the B operands of GEMM 2
@@ -708,6 +741,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #undef FUSED_DMA_PIECE
 }
 
+#define FUSED_OPT 115       // production scheduling options (OPT bits 0, 1, 4, 5, 6 of the kernel)
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
 template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0, int OPT = 0>
@@ -738,7 +772,7 @@ template <typename T, bool L0, bool GNP, int TAIL, typename... A>
 hipError_t launch_fused_opt(A... args) {
   switch (g_fused_opt) {
     case 0: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 0>(args...);
-    default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 19>(args...);
+    default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 }
 

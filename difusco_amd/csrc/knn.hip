@@ -38,7 +38,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const double* __restri
   unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem);
   int* sidx = reinterpret_cast<int*>(skey + kp);
   unsigned* hist = reinterpret_cast<unsigned*>(sidx + kp);
-  unsigned* misc = hist + 256;        // [0] selected count, [1] ties taken
+  unsigned* misc = hist + 256;        // [0] selected count, [2] number of keys equal to the k-th
   unsigned long long* keys = IN_LDS ? reinterpret_cast<unsigned long long*>(misc + 8) : scratch + (long long)blockIdx.x * n;
   const int tid = threadIdx.x;
 
@@ -92,17 +92,43 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const double* __restri
       }
     }
     __syncthreads();
-    // ties: ascending index order needs a serial pass; they are rare (exact float64 equality), so one thread does it
+    // keys equal to kth: the `want` lowest indices are taken (want >= 1: the k-th key itself).  Every thread collects the
+    // ties of its strided share into a list (the histogram's LDS, free now); there are almost always exactly `want` = 1
+    // of them.  One thread orders the list by index and appends the first `want`; only when more than 256 keys tie does
+    // it fall back to the serial scan over all n keys.
+    if (tid == 0) misc[2] = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += KNN_THREADS)
+      if (keys[j] == kth) {
+        const unsigned t = atomicAdd(&misc[2], 1u);
+        if (t < 256u) hist[t] = (unsigned)j;
+      }
+    __syncthreads();
     if (tid == 0) {
       unsigned s = misc[0];
-      int taken = 0;
-      for (int j = 0; j < n && taken < want; ++j)
-        if (keys[j] == kth) {
-          skey[s] = kth;
-          sidx[s] = j;
-          ++s;
-          ++taken;
+      const unsigned nt = misc[2];
+      if (nt <= 256u) {
+        for (unsigned a = 1; a < nt; ++a) {                 // insertion sort of the (tiny) tie list by index
+          const unsigned v = hist[a];
+          unsigned b = a;
+          for (; b > 0 && hist[b - 1] > v; --b) hist[b] = hist[b - 1];
+          hist[b] = v;
         }
+        for (int t = 0; t < want && t < (int)nt; ++t) {
+          skey[s] = kth;
+          sidx[s] = (int)hist[t];
+          ++s;
+        }
+      } else {
+        int taken = 0;
+        for (int j = 0; j < n && taken < want; ++j)
+          if (keys[j] == kth) {
+            skey[s] = kth;
+            sidx[s] = j;
+            ++s;
+            ++taken;
+          }
+      }
     }
     __syncthreads();
     // ---- bitonic sort of kp (key, index) pairs ----

@@ -277,9 +277,9 @@ int difusco_debug_set(int key, int value);   /* key 3: 0 = do not
                                               * fold the first layer's table lookup into the fused kernel (A/B);
                                               * key 4: 0 = head statistics by a separate pass over e (A/B);
                                               * key 6: extra dynamic LDS bytes for the fused kernel (occupancy probe);
-                                              * key 7: scheduling options of the fused kernel (bit 0 XCD-contiguous
-                                              * tile ranges, bit 1 alternating MFMA accumulator chains; results are
-                                              * bit-identical for every value) */
+                                              * key 7: 0 = fused kernel without its scheduling options (XCD-contiguous
+                                              * tile ranges, alternating MFMA chains, non-temporal e stream, two-stage e
+                                              * prefetch, split LayerNorm reductions) for A/B; non-zero = production */
 /* key 1: device buffer [n_tiles][8] of uint64 receiving s_memtime stamps of the fused kernel's phases
  * (NULL disables; profiling only). */
 int difusco_debug_set_ptr(int key, void* p);

@@ -71,7 +71,7 @@ L.difusco_debug_set(0, 0)
 L.difusco_debug_set(7, 0)
 # the scheduling options must not change a single bit
 outs = []
-OPTS = (0, 19)
+OPTS = (0, 115)
 for opt in OPTS:
     L.difusco_debug_set(7, opt)
     e, h = e0.clone(), h0.clone()

@@ -204,6 +204,15 @@ def test_knn_graph_ties_and_errors(dev):
         assert ei[i].tolist() == order
     with pytest.raises(_lib.DifuscoHipError):
         knn_edge_index_gpu(pts, 7, device=dev)
+    # many exact ties: a 20 x 20 lattice (ties at every rank, collected in parallel) and 700 coincident points (more
+    # than 256 keys equal to the k-th: the serial fallback); lowest indices win in both
+    gx, gy = np.meshgrid(np.arange(20) / 32.0, np.arange(20) / 32.0)
+    for pts, k in [(np.stack([gx.ravel(), gy.ravel()], 1), 9), (np.full((700, 2), 0.25), 5)]:
+        n = pts.shape[0]
+        ei = knn_edge_index_gpu(pts, k, device=dev).cpu().numpy()[1].reshape(n, k)
+        d = ((pts[:, None] - pts[None]) ** 2).sum(-1)
+        ref = np.lexsort((np.broadcast_to(np.arange(n), (n, n)), d), axis=1)[:, :k]
+        assert np.array_equal(ei, ref)
 
 
 def test_tsp_batch_gpu_equals_host_batch(dev):
