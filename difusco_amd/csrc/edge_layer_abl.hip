@@ -19,6 +19,9 @@ hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS) {
     case 22: return launch_fused_t<FFp16, 16 + 32768, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);   // stamps, no e stream
     case 23: return launch_fused_t<FFp16, 16 + 16384, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);   // stamps, no stage refills / barriers
     case 24: return launch_fused_t<FFp16, 16 + 1, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);       // stamps, no gathers
+    case 27: return launch_fused_t<FFp16, 16 + 65536, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);     // stamps, stage requests not waited for
+    case 28: return launch_fused_t<FFp16, 16 + 131072, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);    // stamps, no stage barrier
+    case 29: return launch_fused_t<FFp16, 16 + 196608, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);    // stamps, neither (requests still issued)
     default: return hipErrorInvalidValue;
   }
 #undef ABL_ARGS

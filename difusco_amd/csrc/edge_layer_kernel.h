@@ -180,6 +180,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   constexpr bool kDma = (ABL & 2048) == 0;                          // weight stages by LDS-DMA (else registers)
   // profiling only (wrong results): matrix phases without stage refills and barriers / without the e stream
   constexpr bool kNoSync = (ABL & 16384) != 0, kNoE = (ABL & 32768) != 0;
+  // profiling only (races, wrong results): stage requests never waited for / no stage barrier
+  constexpr bool kNoWait = (ABL & 65536) != 0, kNoBar = (ABL & 131072) != 0;
   static_assert(kDma || !G_::ALIAS, "geometry 40 has no register-staged variant");
   constexpr int RING = kDma ? 2 : 4;   // beside LDS-DMA staging every load is drained at the stage barrier
   v4f er[RING][2];
@@ -293,10 +295,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // stream on the DMA queue as well, the two youngest requests are slab t+2 of e, which may stay in flight.
 #define FUSED_PIPE_END(t)                                                        \
   if (!kNoSync && (t) + 1 < NSTAGE) {                                            \
-    if constexpr (kDma) {                                                        \
+    if constexpr (kDma && !kNoWait) {                                            \
       __builtin_amdgcn_s_waitcnt(0x0F70);                            /* vmcnt(0) */ \
     }                                                                            \
-    __syncthreads();                                                             \
+    if constexpr (!kNoBar) __syncthreads();                                      \
   }
 
   static_assert(!L0 || kDma, "the first-layer variant exists for the LDS-DMA staging only");
@@ -440,8 +442,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #undef FUSED_FRAG1
     if constexpr (kDeepE) {
       if (!kNoE && t + RING < 16) {
-        __builtin_amdgcn_s_waitcnt(0x0F72);      // vmcnt(2): everything but this stage's two e loads
-        __syncthreads();
+        if constexpr (!kNoWait) __builtin_amdgcn_s_waitcnt(0x0F72);      // vmcnt(2): everything but this stage's two e loads
+        if constexpr (!kNoBar) __syncthreads();
       } else {
         FUSED_PIPE_END(t)
       }
