@@ -18,10 +18,9 @@
 //     {0..3, 8..11, 4..7, 12..15}).
 //   * fp32 operands are split into two 16-bit planes (fp16: 22 significand bits, or bf16) and multiplied
 //     with 3 MFMA products (hi*hi, hi*lo, lo*hi), accumulated in fp32 (see linear_split.hip).
-// A wave owns a 32-edge tile end to end; a workgroup is NW = 4 waves (two workgroups per CU, whose phases drift
-// apart so that one's MFMA phases overlap the other's VALU / address-heavy epilogue) or NW = 8 (one per CU, half
-// the L2 weight traffic, phases in lock step) - see fused::Geo; 4 measured ~10 % faster.
-// Weights stream through LDS in stages of 64 NW rows of 32 bytes x 2 planes ([256 rows][16 k] slabs for GEMM 1,
+// A wave owns a 32-edge tile end to end; a workgroup is 4 waves (two workgroups per CU, whose phases drift
+// apart so that one's MFMA phases overlap the other's VALU / address-heavy epilogue) - see fused::Geo.
+// Weights stream through LDS in stages of 256 rows of 32 bytes x 2 planes ([256 rows][16 k] slabs for GEMM 1,
 // [64 rows][16 k] sub-slabs of one output quarter for GEMM 2), double buffered, filled by LDS-DMA
 // (buffer_load_dwordx4 ... lds, no staging registers), one barrier per stage; the rows are XOR-swizzled so every
 // 16-lane group of ds_read_b128 hits 16 distinct 16-byte bank slots without padding (the swizzle is applied to the
@@ -50,41 +49,33 @@ constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregati
 enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT, P_TAB0, P_TAB1, P_CE0, P_CE1, P_COUNT };
 // P_TAB*: layer-0 input table rows; P_CE*: C (weight of GEMM 1) applied to those rows
 
-// Workgroup geometry (template parameter NW of the kernel is a geometry code).  A workgroup is WAVES tiles of 32
-// edges; a weight stage holds ENT rows of 32 bytes per plane:
-//   code 8 : 8 waves, 512 rows (32 KiB / stage), 16 stages, ONE workgroup per CU: every weight byte fetched from L2
-//            serves 256 edges, but all 8 waves walk the phases (GEMM 1, epilogue, GEMM 2) in lock step;
-//   code 4 : 4 waves, 256 rows (16 KiB / stage), 32 stages, TWO workgroups per CU that drift apart, so one
-//            workgroup's MFMA phases overlap the other's VALU / address-unit heavy epilogue;
-//   code 40: 4 waves, 512 rows (32 KiB / stage), 16 stages, two workgroups per CU: half the barriers of code 4.
-//            The 2 x 32 KiB of stage buffers only fit beside the aggregation scratch because the scratch ALIASES
-//            stage buffer 1 (+ 2 KiB): the scratch is used between the GEMMs only, the last GEMM 1 stage is the last
-//            reader of buffer 1 (barrier), and the first refill of buffer 1 in GEMM 2 waits for a barrier after the
-//            epilogue.  Measured: barriers + stage refills cost 0.09 ms per GEMM phase with 16 KiB stages.
+// Workgroup geometry (template parameter NW = 4, the only one kept): a workgroup is 4 tiles of 32 edges, a weight stage
+// holds ENT = 256 rows of 32 bytes per plane (16 KiB for the two planes, 32 stages per tile), TWO workgroups per CU
+// whose phases drift apart, so that one's MFMA phases overlap the other's VALU / address-unit heavy epilogue.  Measured
+// and dropped (profiles/r01, r02 fused_kernel_study.txt): one 8-wave workgroup per CU (half the L2 weight traffic, phases
+// in lock step: 8 % slower) and 32 KiB stages with the scratch aliasing a stage buffer (half the barriers: 2-4 % slower).
 template <int CODE>
 struct Geo {
-  static constexpr bool ALIAS = CODE == 40;
-  static constexpr int WAVES = CODE == 8 ? 8 : 4;
+  static_assert(CODE == 4, "one workgroup geometry");
+  static constexpr int WAVES = 4;
   static constexpr int THREADS = 64 * WAVES;
-  static constexpr int ENT = CODE == 4 ? 256 : 512;   // entries (32-byte rows) per plane per stage
-  static constexpr int PP = ENT / 32 / WAVES;      // 1 KiB LDS-DMA pieces per wave, plane and stage (2 | 2 | 4)
+  static constexpr int ENT = 256;               // entries (32-byte rows) per plane per stage
+  static constexpr int PP = ENT / 32 / WAVES;   // 1 KiB LDS-DMA pieces per wave, plane and stage (2)
   static constexpr int PLANE = ENT * 16;        // 16-bit elements per plane per stage
   static constexpr int BUF = 2 * PLANE;         // one stage buffer: 2 planes
-  static constexpr int SPS = ENT / 256;         // GEMM 1: slabs per stage
-  static constexpr int NS1 = 16 / SPS;          // GEMM 1 stages
-  static constexpr int KPS = ENT / 64;          // GEMM 2: k slabs per stage
-  static constexpr int SPQ = 16 / KPS;          // GEMM 2: stages per output quarter
-  static constexpr int NSTAGE = NS1 + 4 * SPQ;  // 16 | 32 | 16
-  static constexpr int LDS_W = 2 * BUF * 2;     // bytes, double buffered             65536 | 32768 | 65536
+  static constexpr int SPS = ENT / 256;         // GEMM 1: slabs per stage (1)
+  static constexpr int NS1 = 16 / SPS;          // GEMM 1 stages (16)
+  static constexpr int KPS = ENT / 64;          // GEMM 2: k slabs per stage (4)
+  static constexpr int SPQ = 16 / KPS;          // GEMM 2: stages per output quarter (4)
+  static constexpr int NSTAGE = NS1 + 4 * SPQ;  // 32
+  static constexpr int LDS_W = 2 * BUF * 2;     // bytes, double buffered                               32768
   static constexpr int LDS_P = P_COUNT * H * 4; // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O, table rows (4) 11264
-  static constexpr int LDS_S = WAVES * 32 * SCR_STRIDE * 4;   // bytes                69632 | 34816 | 34816
-  // ALIAS: [buffer 0][buffer 1 = scratch ...][... scratch tail][parameters]; else [buffers][parameters][scratch]
-  static constexpr int OFF_S = ALIAS ? BUF * 2 : LDS_W + LDS_P;
-  static constexpr int OFF_P = ALIAS ? BUF * 2 + LDS_S : LDS_W;
-  static constexpr int LDS_TOTAL = ALIAS ? BUF * 2 + LDS_S + LDS_P : LDS_W + LDS_P + LDS_S;   // 146432 | 78848 | 78848
-  static_assert(!ALIAS || LDS_S >= BUF * 2, "the aliased scratch must cover stage buffer 1");
+  static constexpr int LDS_S = WAVES * 32 * SCR_STRIDE * 4;   // bytes                                  34816
+  static constexpr int OFF_P = LDS_W;           // [buffers][parameters][scratch]
+  static constexpr int OFF_S = LDS_W + LDS_P;
+  static constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;     //                                        78848
 };
-constexpr int geo_waves(int code) { return code == 8 ? 8 : 4; }
+constexpr int geo_waves(int) { return 4; }
 }  // namespace fused
 
 template <typename T, int ABL, int NW, bool L0, bool GNP, int TAIL, int OPT>
@@ -177,13 +168,11 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // layout = 2 KiB per wave and slab, cold HBM reads.
   // A register ring, RING slabs ahead of the MFMAs.  (Routing this stream through LDS-DMA into the idle aggregation
   // scratch was measured 2.5 % slower - profiles/r01/fused_kernel_study.txt - and removed.)
-  constexpr bool kDma = (ABL & 2048) == 0;                          // weight stages by LDS-DMA (else registers)
   // profiling only (wrong results): matrix phases without stage refills and barriers / without the e stream
   constexpr bool kNoSync = (ABL & 16384) != 0, kNoE = (ABL & 32768) != 0;
   // profiling only (races, wrong results): stage requests never waited for / no stage barrier
   constexpr bool kNoWait = (ABL & 65536) != 0, kNoBar = (ABL & 131072) != 0;
-  static_assert(kDma || !G_::ALIAS, "geometry 40 has no register-staged variant");
-  constexpr int RING = kDma ? 2 : 4;   // beside LDS-DMA staging every load is drained at the stage barrier
+  constexpr int RING = 2;
   v4f er[RING][2];
   if constexpr (L0) {
     // no e stream
@@ -196,61 +185,19 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   }
 
   // ---- weight stage streaming ---------------------------------------------------------------------
-  // A stage is 512 rows of 32 bytes per plane (32 KiB for the two planes):
-  //   stage t < 8 : GEMM 1, slabs 2t, 2t+1 of C;  entry = sub * 256 + weight row  (sub = slab - 2t)
-  //   stage 8 + u : GEMM 2, output quarter qt = u >> 1 (64 features), slabs 8 kc .. 8 kc + 7 of W_o (kc = u & 1);
-  //                 entry = ksl * 64 + (row - 64 qt)
-  // Two 16-byte chunks per thread per plane.  Stage t lives in LDS buffer t & 1; its global loads are issued
-  // at the top of iteration t - 1 and parked in LDS at its end: 48 MFMAs per wave cover the L2 latency, and
-  // there is one barrier per 48 MFMAs.
-  // source of chunk c (entry = c >> 1, half = c & 1) of stage t = uniform stage base + a per-thread offset that does
-  // not depend on t (one for the GEMM 1 stage shape, one for the GEMM 2 shape)
-  unsigned voff1[2], voff2[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + G_::THREADS * i, entry = c >> 1, half = c & 1;
-    voff1[i] = (entry >> 8) * 4096 + (entry & 255) * 16 + half * 8;
-    voff2[i] = (entry >> 6) * 4096 + (entry & 63) * 16 + half * 8;
-  }
-  auto stage_base = [&](int t) -> const unsigned short* {      // wave uniform
-    if (t < NS1) return c_planes + (long long)(SPS * t) * 4096;
-    const int u = t - NS1, qt = u / SPQ, kc = u % SPQ;
-    return o_planes + (long long)(KPS * kc) * 4096 + 64 * qt * 16;
-  };
-  v4u wr[2][2];   // [plane][chunk]
-#define FUSED_LOAD_STAGE(t)                                                        \
-  {                                                                                \
-    const unsigned short* sb = stage_base(t);                                      \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
-      const unsigned vo = (t) < NS1 ? voff1[i] : voff2[i];                         \
-      wr[0][i] = *reinterpret_cast<const v4u*>(sb + vo);                           \
-      wr[1][i] = *reinterpret_cast<const v4u*>(sb + plane_stride + vo);            \
-    }                                                                              \
-  }
-#define FUSED_STORE_STAGE(t)                                                       \
-  {                                                                                \
-    unsigned short* dst = wbuf + ((t) & 1) * BUF;                                  \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
-      const int c = tid + G_::THREADS * i;                                         \
-      const int off = wslot(c >> 1, c & 1);                                        \
-      *reinterpret_cast<v4u*>(dst + off) = wr[0][i];                               \
-      *reinterpret_cast<v4u*>(dst + PLANE + off) = wr[1][i];                       \
-    }                                                                              \
-  }
-  // Write-early pipeline.  Iteration t: park stage t+1 in LDS (its loads were issued one whole iteration ago),
-  // issue the loads of stage t+2 (pinned at the top by the sched_barrier: the register-pressure-driven scheduler
-  // otherwise sinks them next to their use and exposes the L2 latency once per stage), multiply stage t, barrier.
-  // The first GEMM 2 stage pair straddles the epilogue: stage NS1+1 is fetched after it, not held across it.
-  // LDS-DMA staging (production; ABL & 2048 selects the older register-staged path for A/B): global_load_lds_dwordx4
-  // moves 1 KiB per wave instruction from global memory
-  // straight into the stage buffer - no staging registers, no ds_write.  The LDS image is the same swizzled image
-  // the register path builds: lane L of wave w, instruction i (0, 1) fills slot (2 w + i) * 64 + L of a plane, i.e.
-  // entry = (2 w + i) * 32 + (L >> 1), and fetches the half that belongs there (the XOR of wslot applied on the
+  // A stage is ENT rows of 32 bytes per plane (16 KiB for the two planes):
+  //   stage t < NS1 : GEMM 1, slab t of C;  entry = weight row
+  //   stage NS1 + u : GEMM 2, output quarter qt = u / SPQ (64 features), slabs KPS kc .. KPS kc + KPS - 1 of W_o (kc = u % SPQ);
+  //                   entry = ksl * 64 + (row - 64 qt)
+  // Stage t lives in LDS buffer t & 1 and is filled by LDS-DMA: buffer_load_dwordx4 ... lds moves 1 KiB per wave
+  // instruction from global memory straight into the stage buffer - no staging registers, no ds_write.  The LDS image
+  // is swizzled (wslot): lane L of wave w, piece i fills slot (PP w + i) * 64 + L of a plane, i.e.
+  // entry = (PP w + i) * 32 + (L >> 1), and fetches the half that belongs there (the XOR of wslot applied on the
   // source side; both halves of an entry are adjacent in global memory, so coalescing is unchanged).
   // Protocol: iteration t requests stage t+1 into the other buffer (everybody left it at the last barrier),
-  // multiplies stage t, then waits for its own requests (vmcnt(0)) before the barrier.
-  unsigned dvoff1 = 0, dvoff2 = 0;
-  if constexpr (kDma) {
+  // multiplies stage t, then waits for its own requests before the barrier.
+  unsigned dvoff1, dvoff2;
+  {
     const int entry0 = (PP * wave) * 32 + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
     dvoff1 = (entry0 >> 8) * 4096 + (entry0 & 255) * 16 + half * 8;
     dvoff2 = (entry0 >> 6) * 4096 + (entry0 & 63) * 16 + half * 8;
@@ -277,17 +224,9 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       _Pragma("unroll") for (int i = 0; i < PP; ++i) FUSED_DMA_PIECE(t, pl, i)                               \
   }
 #define FUSED_PIPE_BEGIN(t)                                         \
-  if constexpr (kNoSync) {                                          \
-  } else if constexpr (kDma) {                                      \
-    if (G_::ALIAS && (t) == NS1) __syncthreads();   /* every wave has left the scratch = stage buffer 1 */ \
+  if constexpr (!kNoSync) {                                         \
     if ((t) + 1 < NSTAGE) {                                         \
       FUSED_DMA_STAGE((t) + 1)                                      \
-      __builtin_amdgcn_sched_barrier(0);                            \
-    }                                                               \
-  } else {                                                          \
-    if ((t) + 1 < NSTAGE) FUSED_STORE_STAGE((t) + 1)                \
-    if ((t) + 2 < NSTAGE && (t) + 2 != NS1 + 1) {                   \
-      FUSED_LOAD_STAGE((t) + 2)                                     \
       __builtin_amdgcn_sched_barrier(0);                            \
     }                                                               \
   }
@@ -295,15 +234,14 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // stream on the DMA queue as well, the two youngest requests are slab t+2 of e, which may stay in flight.
 #define FUSED_PIPE_END(t)                                                        \
   if (!kNoSync && (t) + 1 < NSTAGE) {                                            \
-    if constexpr (kDma && !kNoWait) {                                            \
+    if constexpr (!kNoWait) {                                                    \
       __builtin_amdgcn_s_waitcnt(0x0F70);                            /* vmcnt(0) */ \
     }                                                                            \
     if constexpr (!kNoBar) __syncthreads();                                      \
   }
 
-  static_assert(!L0 || kDma, "the first-layer variant exists for the LDS-DMA staging only");
   if constexpr (L0) { FUSED_DMA_STAGE(NS1) }           // no GEMM 1: the stage stream starts with GEMM 2
-  else if constexpr (kDma) { FUSED_DMA_STAGE(0) } else { FUSED_LOAD_STAGE(0) }
+  else { FUSED_DMA_STAGE(0) }
 
   // layer parameters -> LDS (thread = feature)
   if (tid < H) {
@@ -332,12 +270,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   const float* ni = node4 + (long long)i_node * 4 * H;
 
   v16f acc1[8];
-  if constexpr (kDma) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage 0 has landed
-  } else {
-    FUSED_STORE_STAGE(0)
-    FUSED_LOAD_STAGE(1)
-  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage 0 has landed
   __syncthreads();
 
   FUSED_STAMP(1)
@@ -366,7 +299,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // stage then ends with vmcnt(2) instead of vmcnt(0): the weight pieces have landed (requests complete in order), the
   // e loads stay in flight across the barrier and are waited for at the end of the NEXT stage.
   constexpr bool kDeepE = (OPT & 32) != 0;
-  static_assert(!kDeepE || (kDma && SPS == 1 && RING == 2), "OPT bit 5 is written for the 16 KiB LDS-DMA stages");
+  static_assert(!kDeepE || (SPS == 1 && RING == 2), "OPT bit 5 is written for the 16 KiB stages");
 #pragma unroll
   for (int t = 0; t < (L0 ? 0 : NS1); ++t) {
     if constexpr (!kDeepE) { FUSED_PIPE_BEGIN(t) }
@@ -616,7 +549,6 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 
   FUSED_STAMP(6)
   // ================================ GEMM 2 (four output quarters of 64 features) ======================
-  if constexpr (!kDma) { FUSED_LOAD_STAGE(NS1 + 1) }
   constexpr bool skip_gemm2 = (ablate & 8) != 0;   // (barriers must still be executed by every wave)
   constexpr bool skip_out = (ablate & 32) != 0;    // GEMM 2 without residual read / e store
   constexpr bool skip_mm2 = (ablate & 64) != 0;    // GEMM 2 output path without its MFMAs
@@ -735,8 +667,6 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     }
   }
 #undef FUSED_STAMP
-#undef FUSED_LOAD_STAGE
-#undef FUSED_STORE_STAGE
 #undef FUSED_PIPE_BEGIN
 #undef FUSED_PIPE_END
 #undef FUSED_DMA_STAGE

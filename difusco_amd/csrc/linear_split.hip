@@ -206,12 +206,10 @@ static hipError_t launch_split(const float* x, const unsigned short* wp, long lo
                                const float* residual, float* y, long long m, int n_out, long long ldy, hipStream_t stream,
                                int tiled_out, const int* gen_perm = nullptr, const float* gen_dimt = nullptr) {
   constexpr size_t lds = (size_t)NS * (128 + FB) * 24 * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_split_kernel<K, FB, NS, T, GEN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static std::atomic<unsigned long long> attr_devices{0};
+  {
+    hipError_t e = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&linear_rows_split_kernel<K, FB, NS, T, GEN>), (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   dim3 grid((unsigned)((m + 127) / 128), (unsigned)(n_out / FB));
   hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS, T, GEN>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
@@ -235,7 +233,8 @@ hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long
     return launch_split<KK, FBB, 2, Fp16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out);    \
   }
   // few row tiles (node rows): 128-column blocks give twice the workgroups, i.e. two per CU instead of one
-  // (node linears 0.49 -> 0.42 ms/step at 8000 rows x 1024 outputs; 64-column blocks measured slower: 0.475)
+  // (node linears 0.49 -> 0.42 ms/step at 8000 rows x 1024 outputs; 64-column blocks measured slower: 0.475;
+  // round 2: two / four k slabs per LDS step - half / a quarter of the barriers - measured 0.433 / 0.546 vs 0.431 ms/step)
   if (k == 256 && !tiled_out && n_out % 128 == 0 && ((m + 127) / 128) * (n_out / 256) < 512) {
     DIFUSCO_SPLIT_CASE(256, 128)
   }
