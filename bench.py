@@ -182,6 +182,8 @@ def main():
                          "over the whole sharded batch (one all-reduce of 65 doubles per step)")
     ap.add_argument("--fused-opt", type=int, default=None, help="A/B: scheduling options of the fused kernel "
                     "(difusco_debug_set key 7: 0 = all off, default = production set)")
+    ap.add_argument("--node-linear-depth", type=int, default=None, choices=[1, 4],
+                    help="A/B: k steps of global-load lookahead in the node-row linear (difusco_debug_set key 8)")
     ap.add_argument("--no-node-reorder", action="store_true", help="A/B: keep the caller's node numbering (no Morton order)")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32 (v_mfma_f32_32x32x2_f32) sub-record")
     ap.add_argument("--precision", default="fp16x3", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
@@ -234,6 +236,8 @@ def main():
         _lib.check(_lib.lib().difusco_debug_set(4, 0))
     if args.fused_opt is not None:
         _lib.check(_lib.lib().difusco_debug_set(7, args.fused_opt))
+    if args.node_linear_depth is not None:
+        _lib.check(_lib.lib().difusco_debug_set(8, args.node_linear_depth))
     from difusco_amd.dist import engine_from_broadcast, gn_allreduce, shard_range
     from difusco_amd.engine import DenoiseEngine
     from difusco_amd.models import MISModel, TSPModel

@@ -510,6 +510,7 @@ int difusco_debug_set(int key, int value) {
   if (key == 4) { difusco::g_fused_gn_fold = value; return DIFUSCO_OK; }
   if (key == 6) { difusco::g_fused_lds_pad = value; return DIFUSCO_OK; }
   if (key == 7) { difusco::g_fused_opt = value; return DIFUSCO_OK; }
+  if (key == 8 && (value == 1 || value == 4)) { difusco::g_node_linear_depth = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }
 

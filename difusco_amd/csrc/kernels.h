@@ -66,6 +66,7 @@ hipError_t launch_edge_layer_fused_tail(int mode, int tail, float* e, const floa
 extern int g_fused_gn_fold;
 extern int g_fused_lds_pad;
 extern int g_fused_opt;
+extern int g_node_linear_depth;
 extern unsigned long long* g_fused_dbg;
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,

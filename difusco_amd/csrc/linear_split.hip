@@ -65,7 +65,11 @@ struct Fp16 {
 // GEN: the rows of X are not read but generated - ScalarEmbeddingSine of one scalar per row (gnn_encoder.py:230-249):
 // X[r][c] = sin / cos (x[r] / dim_t[c]) for even / odd c, the arithmetic of scalar_embed_kernel.  X then carries the
 // scalars (gen_x, indexed through gen_perm) and the E x H embedding never exists in memory.
-template <int K, int FB, int NS, typename T, bool GEN = false>
+// D: how many k steps ahead the global loads of a step are issued (register ring of D slots, loop fully unrolled).
+// D = 1 for the E-row linears (thousands of workgroups hide the latency).  The node-row linear has one or two workgroups
+// per CU and its weight planes come from MALL (the e stream of the edge kernels sweeps the L2 between two layers), so with
+// D = 1 every one of its 16 k steps waits for a ~2,000-cycle round trip: D = 4 keeps four steps in flight.
+template <int K, int FB, int NS, typename T, bool GEN = false, int D = 1>
 __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* __restrict__ X,
                                                                     const unsigned short* __restrict__ Wp,
                                                                     long long plane_stride,  // elements between planes
@@ -86,8 +90,17 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
   unsigned short* Ws = smem_s + NS * RB * RS;          // [NS][FB][RS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const long long r0 = (long long)blockIdx.x * RB;
-  const int f0 = blockIdx.y * FB;
+  // D > 1 (node-row linear): 1-D grid mapped so that the column blocks of one row block run on ONE XCD (workgroup b runs on
+  // XCD b % 8), back to back - the X rows are then fetched into one L2 once instead of into eight.
+  int rb_i = blockIdx.x, cb_i = blockIdx.y;
+  if constexpr (D > 1) {
+    const int ncb = n_out_total / FB, slot = (int)blockIdx.x >> 3;
+    rb_i = (slot / ncb) * 8 + ((int)blockIdx.x & 7);
+    cb_i = slot % ncb;
+    if ((long long)rb_i * RB >= M) return;
+  }
+  const long long r0 = (long long)rb_i * RB;
+  const int f0 = cb_i * FB;
 
   v16f acc[NB];
 #pragma unroll
@@ -95,10 +108,10 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
 
-  v4f xr[2];
-  v4u wr[NS][WV];
+  v4f xr_[D][2];
+  v4u wr_[D][NS][WV];
 
-#define DIFUSCO_LOAD(KT)                                                                              \
+#define DIFUSCO_LOAD(KT, SLOT)                                                                            \
   {                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
       const int idx = tid + 256 * i;                                                                  \
@@ -110,10 +123,10 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
           const int c = (KT) + c4 * 4 + q;                                                            \
           const float v = xv / gen_dimt[c];                                                           \
-          xr[i][q] = (c & 1) ? cosf(v) : sinf(v);                                                     \
+          xr_[SLOT][i][q] = (c & 1) ? cosf(v) : sinf(v);                                                     \
         }                                                                                             \
       } else {                                                                                        \
-        xr[i] = *reinterpret_cast<const v4f*>(X + gr * K + (KT) + c4 * 4);                            \
+        xr_[SLOT][i] = *reinterpret_cast<const v4f*>(X + gr * K + (KT) + c4 * 4);                            \
       }                                                                                               \
     }                                                                                                 \
     const unsigned short* wslab = Wp + ((long long)((KT) / BK) * n_out_total + f0) * BK;              \
@@ -121,16 +134,16 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
       _Pragma("unroll") for (int i = 0; i < WV; ++i) {                                                \
         int c = tid + 256 * i;                                                                        \
         if (FB * 2 % 256 != 0) c = c < FB * 2 ? c : FB * 2 - 1;                                       \
-        wr[p][i] = *reinterpret_cast<const v4u*>(wslab + p * plane_stride + (long long)c * 8);        \
+        wr_[SLOT][p][i] = *reinterpret_cast<const v4u*>(wslab + p * plane_stride + (long long)c * 8);        \
       }                                                                                               \
     }                                                                                                 \
   }
-#define DIFUSCO_STORE()                                                                               \
+#define DIFUSCO_STORE(SLOT)                                                                           \
   {                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
       const int idx = tid + 256 * i;                                                                  \
       const int row = idx >> 2, c4 = idx & 3;                                                         \
-      float a = xr[i][0], b = xr[i][1], c = xr[i][2], d = xr[i][3];                                   \
+      float a = xr_[SLOT][i][0], b = xr_[SLOT][i][1], c = xr_[SLOT][i][2], d = xr_[SLOT][i][3];                                   \
       _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                \
         v2u pk;                                                                                       \
         pk[0] = T::split_pair(a, b);                                                                  \
@@ -143,21 +156,24 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
       _Pragma("unroll") for (int i = 0; i < WV; ++i) {                                                \
         int c = tid + 256 * i;                                                                        \
         if (FB * 2 % 256 != 0) c = c < FB * 2 ? c : FB * 2 - 1;                                       \
-        *reinterpret_cast<v4u*>(Ws + (p * FB + (c >> 1)) * RS + (c & 1) * 8) = wr[p][i];             \
+        *reinterpret_cast<v4u*>(Ws + (p * FB + (c >> 1)) * RS + (c & 1) * 8) = wr_[SLOT][p][i];             \
       }                                                                                               \
     }                                                                                                 \
   }
 
-  DIFUSCO_LOAD(0)
-  DIFUSCO_STORE()
+  constexpr int NSTEP = K / BK;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < NSTEP) DIFUSCO_LOAD(d * BK, d)
+  DIFUSCO_STORE(0)
   __syncthreads();
 
   const unsigned short* xrow = Xs + (wave * 32 + l31) * RS + hh * 8;
   const unsigned short* wrow = Ws + l31 * RS + hh * 8;
 
-  for (int kt = 0; kt < K; kt += BK) {
-    const int kn = (kt + BK) < K ? kt + BK : kt;
-    DIFUSCO_LOAD(kn)
+#pragma unroll
+  for (int st = 0; st < NSTEP; ++st) {
+    if (st + D < NSTEP) DIFUSCO_LOAD((st + D) * BK, st % D)      // slot st % D was parked in LDS before this step
     typedef typename T::frag frag;
     frag xb[NS];
 #pragma unroll
@@ -177,9 +193,11 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
       acc[nb] = T::mfma(wa[0], xb[1], acc[nb]);
       acc[nb] = T::mfma(wa[0], xb[0], acc[nb]);
     }
-    __syncthreads();
-    DIFUSCO_STORE()
-    __syncthreads();
+    if (st + 1 < NSTEP) {
+      __syncthreads();
+      DIFUSCO_STORE((st + 1) % D)
+      __syncthreads();
+    }
   }
 #undef DIFUSCO_LOAD
 #undef DIFUSCO_STORE
@@ -201,21 +219,24 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
   }
 }
 
-template <int K, int FB, int NS, typename T, bool GEN = false>
+template <int K, int FB, int NS, typename T, bool GEN = false, int D = 1>
 static hipError_t launch_split(const float* x, const unsigned short* wp, long long plane_stride, const float* bias,
                                const float* residual, float* y, long long m, int n_out, long long ldy, hipStream_t stream,
                                int tiled_out, const int* gen_perm = nullptr, const float* gen_dimt = nullptr) {
   constexpr size_t lds = (size_t)NS * (128 + FB) * 24 * sizeof(unsigned short);
   static std::atomic<unsigned long long> attr_devices{0};
   {
-    hipError_t e = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&linear_rows_split_kernel<K, FB, NS, T, GEN>), (int)lds);
+    hipError_t e = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&linear_rows_split_kernel<K, FB, NS, T, GEN, D>), (int)lds);
     if (e != hipSuccess) return e;
   }
   dim3 grid((unsigned)((m + 127) / 128), (unsigned)(n_out / FB));
-  hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS, T, GEN>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
+  if (D > 1) grid = dim3((unsigned)(8 * (((m + 127) / 128 + 7) / 8) * (n_out / FB)), 1);
+  hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS, T, GEN, D>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
                      bias, residual, y, m, ldy, tiled_out, gen_perm, gen_dimt);
   return hipGetLastError();
 }
+
+int g_node_linear_depth = 4;     // k steps of global-load lookahead in the node-row linear (difusco_debug_set key 8: 1 or 4)
 
 // wp: first plane of the chosen element type, plane p at wp + p*plane_stride, each [K/16][n_out][16]
 // (k-permuted).  mode: 1 = bf16 x 2 planes (3 products), 2 = bf16 x 3 planes (6 products),
@@ -236,6 +257,10 @@ hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long
   // (node linears 0.49 -> 0.42 ms/step at 8000 rows x 1024 outputs; 64-column blocks measured slower: 0.475;
   // round 2: two / four k slabs per LDS step - half / a quarter of the barriers - measured 0.433 / 0.546 vs 0.431 ms/step)
   if (k == 256 && !tiled_out && n_out % 128 == 0 && ((m + 127) / 128) * (n_out / 256) < 512) {
+    if (g_node_linear_depth == 4) {      // (difusco_debug_set key 8 = 1 restores the one-step lookahead for A/B)
+      if (mode == 1) return launch_split<256, 128, 2, Bf16, false, 4>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out);
+      if (mode == 3) return launch_split<256, 128, 2, Fp16, false, 4>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out);
+    }
     DIFUSCO_SPLIT_CASE(256, 128)
   }
   DIFUSCO_SPLIT_CASE(256, 256)

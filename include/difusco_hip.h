@@ -279,7 +279,8 @@ int difusco_debug_set(int key, int value);   /* key 3: 0 = do not
                                               * key 6: extra dynamic LDS bytes for the fused kernel (occupancy probe);
                                               * key 7: 0 = fused kernel without its scheduling options (XCD-contiguous
                                               * tile ranges, alternating MFMA chains, non-temporal e stream, two-stage e
-                                              * prefetch, split LayerNorm reductions) for A/B; non-zero = production */
+                                              * prefetch, split LayerNorm reductions) for A/B; non-zero = production;
+                                              * key 8: k steps of load lookahead in the node-row linear (1 or 4; A/B) */
 /* key 1: device buffer [n_tiles][8] of uint64 receiving s_memtime stamps of the fused kernel's phases
  * (NULL disables; profiling only). */
 int difusco_debug_set_ptr(int key, void* p);
