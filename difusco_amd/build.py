@@ -19,6 +19,15 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.p
            os.path.join(os.path.dirname(PKG), "include", "difusco_hip.h")]
 
 
+# per-source compiler options.  The fused edge-layer translation units are compiled with LLVM's iterative-maxocc
+# instruction scheduler: with the default scheduler the kernels need 256 VGPRs and still spill 44-120 B per lane; with this
+# one they need 234-242 and no scratch, and the step is 3.7 % faster (DIFUSCO_FUSED_SCHED=default restores the default).
+_FUSED_SCHED = os.environ.get("DIFUSCO_FUSED_SCHED", "iterative-maxocc")
+EXTRA_FLAGS = {}
+if _FUSED_SCHED != "default":
+    for _src in ("edge_layer.hip", "edge_layer_bf16.hip", "edge_layer_abl.hip"):
+        EXTRA_FLAGS[_src] = ["-mllvm", "-amdgpu-sched-strategy=" + _FUSED_SCHED]
+
 TORCH_LIB_PATH = os.path.join(LIB_DIR, "libdifusco_torch.so")
 TORCH_SRC = os.path.join(CSRC, "torch_ops.cpp")
 
@@ -67,7 +76,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with tempfile.TemporaryDirectory(prefix="difusco_build_") as tmp:
         def compile_one(src):
             obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
-            cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             res = subprocess.run(cmd, capture_output=True, text=True)

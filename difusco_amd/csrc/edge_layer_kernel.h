@@ -111,7 +111,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //          MFMA waits for the result of the one issued right before it.
   //   bit 4  non-temporal accesses for the e stream (see kNt below).
   //   bit 5  two stages of cover for the e stream (kDeepE below);  bit 6  LayerNorm reductions as four partial sums (kPart).
-  // Production = 115 (bits 0, 1, 4, 5, 6): +6 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
+  //   bit 8  GEMM 1 input slabs of e through a buffer resource (kBufRing below).
+  // Production = 371 (bits 0, 1, 4, 5, 6, 8): +10 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
   // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5 do not change a result bit; bit 6
   // changes the summation order of the LayerNorm statistics (fp32 rounding, ~1e-6 on e).
@@ -149,11 +150,28 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // that it does not push the neighbour-table rows and the weight planes - both re-read by every workgroup of the
   // XCD - out of the 4 MiB L2
   constexpr bool kNt = (OPT & 16) != 0;
-  auto ld_e = [&](const float* p) -> v4f {
-    if constexpr (kNt) return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
-    else return *reinterpret_cast<const v4f*>(p);
+  // OPT bit 8: the GEMM 1 input slabs of e are read through a buffer resource over the wave's tile (wave-uniform base in
+  // SGPRs, one 32-bit lane offset, the slab offset in an SGPR) instead of per-lane 64-bit addresses.  Measured together
+  // with the iterative-maxocc instruction scheduler (build.py): no scratch in any variant and +3.7 % on the step.  The
+  // residual loads and the stores keep the global (scalar base + 32-bit offset) form: routing them through the buffer
+  // as well measured the same, and buffer_store_dwordx4 with an SGPR soffset needs a hand-placed wait state on gfx950
+  // (profiles/r02/fused_kernel_study.txt, "buffer stores").
+  constexpr bool kBufRing = (OPT & 256) != 0;
+  typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(etile, 0, 32 * H * 4, 0x00020000);
+  const int loff_b = lane * 16;
+  auto ld_e = [&](int off, bool buf = false) -> v4f {       // off: float offset inside the tile (a constant at every call)
+    if (buf) {
+      const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rs_e, loff_b, off * 4, kNt ? 2 : 0);
+      return __builtin_bit_cast(v4f, r);
+    } else {
+      const float* p = etile + off + loff;
+      if constexpr (kNt) return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+      else return *reinterpret_cast<const v4f*>(p);
+    }
   };
-  auto st_e = [&](float* p, v4f v) {
+  auto st_e = [&](int off, v4f v) {
+    float* p = etile + off + loff;
     if constexpr (kNt) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
     else *reinterpret_cast<v4f*>(p) = v;
   };
@@ -179,8 +197,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   } else {
 #pragma unroll
     for (int d = 0; d < RING; ++d) {
-      er[d][0] = ld_e(etile + d * 512 + loff);
-      er[d][1] = ld_e(etile + (d * 512 + 256) + loff);
+      er[d][0] = ld_e(d * 512, kBufRing);
+      er[d][1] = ld_e((d * 512 + 256), kBufRing);
     }
   }
 
@@ -313,8 +331,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
         c0 = er[ks % RING][0];
         c1 = er[ks % RING][1];
         if (!kDeepE && !kNoE && ks + RING < 16) {
-          er[ks % RING][0] = ld_e(etile + (ks + RING) * 512 + loff);
-          er[ks % RING][1] = ld_e(etile + ((ks + RING) * 512 + 256) + loff);
+          er[ks % RING][0] = ld_e((ks + RING) * 512, kBufRing);
+          er[ks % RING][1] = ld_e(((ks + RING) * 512 + 256), kBufRing);
         }
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -324,8 +342,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       __builtin_amdgcn_sched_barrier(0);
       FUSED_PIPE_BEGIN(t)
       if (!kNoE && t + RING < 16) {
-        er[t % RING][0] = ld_e(etile + (t + RING) * 512 + loff);
-        er[t % RING][1] = ld_e(etile + ((t + RING) * 512 + 256) + loff);
+        er[t % RING][0] = ld_e((t + RING) * 512, kBufRing);
+        er[t % RING][1] = ld_e(((t + RING) * 512 + 256), kBufRing);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -426,6 +444,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     if (b + 1 < 16) {
       if (((b + 1) & 1) == 0) FUSED_GATHER(b + 1, 0) else FUSED_GATHER(b + 1, 1)
     }
+    if constexpr ((OPT & 256) != 0) __builtin_amdgcn_sched_barrier(0);
     const int nb = b >> 1, nq = nb & 1;
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) {
@@ -452,19 +471,26 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       __builtin_amdgcn_wave_barrier();
       if constexpr (!(ablate & 2)) {
         const int f = 64 * rnd + lane;
-        float v[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] = scr[k * SCR_STRIDE + lane];
+        // two halves of 16 rows: 32 values in flight at once is the register peak of the kernel (128 accumulators + the
+        // gather buffers are live here) and made the compiler spill accumulators
         float accv = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-          if (k > 0 && ((bnd >> k) & 1u)) {                      // wave-uniform branch
-            const int node = __builtin_amdgcn_readlane(i_node, k - 1);
-            float* dst = (k == first_end) ? part0 : direct + (long long)node * H;
-            dst[f] = accv;
-            accv = 0.0f;
+        for (int half = 0; half < 2; ++half) {
+          float v[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v[k] = scr[(16 * half + k) * SCR_STRIDE + lane];
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) {
+            const int k = 16 * half + kk;
+            if (k > 0 && ((bnd >> k) & 1u)) {                      // wave-uniform branch
+              const int node = __builtin_amdgcn_readlane(i_node, k - 1);
+              float* dst = (k == first_end) ? part0 : direct + (long long)node * H;
+              dst[f] = accv;
+              accv = 0.0f;
+            }
+            accv += v[kk];
           }
-          accv += v[k];
+          __builtin_amdgcn_sched_barrier(0);
         }
         float* dst = (first_end == 32) ? part0 : part1;
         dst[f] = accv;
@@ -570,7 +596,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             if constexpr (L0) ein[nbp][g] = *reinterpret_cast<const v4f*>(prm + l0_row + 64 * qt + 32 * nbp + 8 * g + 4 * hh);
-            else ein[nbp][g] = ld_e(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff);
+            else ein[nbp][g] = ld_e(((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256));
           }
       }
       const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
@@ -641,7 +667,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           v4f v;
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
-          st_e(etile + ((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256) + loff, v);
+          st_e(((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256), v);
           if constexpr (GNP) {
             gs[nbp * 4 + g] = (v[0] + v[1]) + (v[2] + v[3]);
             gq[nbp * 4 + g] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -673,7 +699,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #undef FUSED_DMA_PIECE
 }
 
-#define FUSED_OPT 115       // production scheduling options (OPT bits 0, 1, 4, 5, 6 of the kernel)
+#define FUSED_OPT 371       // production scheduling options (OPT bits 0, 1, 4, 5, 6, 8 of the kernel)
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
 template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0, int OPT = 0>
@@ -704,6 +730,7 @@ template <typename T, bool L0, bool GNP, int TAIL, typename... A>
 hipError_t launch_fused_opt(A... args) {
   switch (g_fused_opt) {
     case 0: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 0>(args...);
+    case 115: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 115>(args...);      // (A/B: e stream by 64-bit lane addresses)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 }
