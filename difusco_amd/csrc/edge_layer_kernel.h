@@ -112,7 +112,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //   bit 4  non-temporal accesses for the e stream (see kNt below).
   //   bit 5  two stages of cover for the e stream (kDeepE below);  bit 6  LayerNorm reductions as four partial sums (kPart).
   //   bit 8  GEMM 1 input slabs of e through a buffer resource (kBufRing below).
-  // Production = 371 (bits 0, 1, 4, 5, 6, 8): +10 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
+  //   bit 9  raised issue priority outside the GEMM phases.
+  // Production = 883 (bits 0, 1, 4, 5, 6, 8, 9): +11 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
   // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5 do not change a result bit; bit 6
   // changes the summation order of the LayerNorm statistics (fp32 rounding, ~1e-6 on e).
@@ -406,6 +407,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   }
 
   FUSED_STAMP(4)
+  // OPT bit 9: the latency-bound phases (gathers, gate, neighbour sum, LayerNorms) run at raised issue priority (s_setprio 3):
+  // their dependent VALU chains no longer queue behind the co-resident wave's MFMA issue.  +1.2 % on the step; raising
+  // the prologue and GEMM 2's output phases as well measured 0.5 % less, raising the GEMM phases instead (round 1) lost 1 %.
+  if constexpr ((OPT & 512) != 0) __builtin_amdgcn_s_setprio(3);
   // ================================ epilogue 1 =======================================================
   // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3.
   // Neighbour-table rows are gathered one batch (= 2 quads) ahead of their use.
@@ -573,6 +578,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
     }
 
+  if constexpr ((OPT & 512) != 0) __builtin_amdgcn_s_setprio(0);
   FUSED_STAMP(6)
   // ================================ GEMM 2 (four output quarters of 64 features) ======================
   constexpr bool skip_gemm2 = (ablate & 8) != 0;   // (barriers must still be executed by every wave)
@@ -699,7 +705,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #undef FUSED_DMA_PIECE
 }
 
-#define FUSED_OPT 371       // production scheduling options (OPT bits 0, 1, 4, 5, 6, 8 of the kernel)
+#define FUSED_OPT 883       // production scheduling options (OPT bits 0, 1, 4, 5, 6, 8, 9 of the kernel)
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
 template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0, int OPT = 0>
@@ -731,6 +737,7 @@ hipError_t launch_fused_opt(A... args) {
   switch (g_fused_opt) {
     case 0: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 0>(args...);
     case 115: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 115>(args...);      // (A/B: e stream by 64-bit lane addresses)
+    case 371: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 371>(args...);      // (A/B: no raised issue priority)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 }
