@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //   bit 9  raised issue priority outside the GEMM phases.
   // Production = 883 (bits 0, 1, 4, 5, 6, 8, 9): +11 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
-  // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5 do not change a result bit; bit 6
+  // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5, 8, 9 do not change a result bit; bit 6
   // changes the summation order of the LayerNorm statistics (fp32 rounding, ~1e-6 on e).
   // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
   // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
