@@ -22,6 +22,8 @@ hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS) {
     case 27: return launch_fused_t<FFp16, 16 + 65536, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);     // stamps, stage requests not waited for
     case 28: return launch_fused_t<FFp16, 16 + 131072, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);    // stamps, no stage barrier
     case 29: return launch_fused_t<FFp16, 16 + 196608, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);    // stamps, neither (requests still issued)
+    case 30: return launch_fused_t<FFp16, 16 + 128, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);       // stamps, no B h[i] gathers
+    case 31: return launch_fused_t<FFp16, 16 + 256, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);       // stamps, no A h[j] / V h[j] gathers
     default: return hipErrorInvalidValue;
   }
 #undef ABL_ARGS
