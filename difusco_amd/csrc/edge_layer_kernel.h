@@ -112,10 +112,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //   bit 4  non-temporal accesses for the e stream (see kNt below).
   //   bit 5  two stages of cover for the e stream (kDeepE below);  bit 6  LayerNorm reductions as four partial sums (kPart).
   //   bit 8  GEMM 1 input slabs of e through a buffer resource (kBufRing below).
-  //   bit 9  raised issue priority outside the GEMM phases.
-  // Production = 883 (bits 0, 1, 4, 5, 6, 8, 9): +11 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
+  //   bit 9  raised issue priority outside the GEMM phases;  bit 10  default cache policy for the GEMM 1 slabs of e.
+  // Production = 1907 (bits 0, 1, 4, 5, 6, 8, 9, 10): +14 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
-  // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5, 8, 9 do not change a result bit; bit 6
+  // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5, 8-10 do not change a result bit; bit 6
   // changes the summation order of the LayerNorm statistics (fp32 rounding, ~1e-6 on e).
   // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
   // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
@@ -161,19 +161,23 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(etile, 0, 32 * H * 4, 0x00020000);
   const int loff_b = lane * 16;
+  // OPT bit 10: the GEMM 1 slabs are read with the default cache policy; the residual re-read (last use) and the stores stay
+  // non-temporal.  Measured on one box, graph-steps/s: all three non-temporal 785.1 | slabs default 802.6 | residual default
+  // 765.4 | slabs + residual default 782.5 | stores default 759.4 | slabs + stores default 774.9.
+  constexpr bool kNtRing = kNt && (OPT & 1024) == 0, kNtRes = kNt, kNtSt = kNt;
   auto ld_e = [&](int off, bool buf = false) -> v4f {       // off: float offset inside the tile (a constant at every call)
     if (buf) {
-      const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rs_e, loff_b, off * 4, kNt ? 2 : 0);
+      const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rs_e, loff_b, off * 4, kNtRing ? 2 : 0);
       return __builtin_bit_cast(v4f, r);
     } else {
       const float* p = etile + off + loff;
-      if constexpr (kNt) return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+      if constexpr (kNtRes) return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
       else return *reinterpret_cast<const v4f*>(p);
     }
   };
   auto st_e = [&](int off, v4f v) {
     float* p = etile + off + loff;
-    if constexpr (kNt) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+    if constexpr (kNtSt) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
     else *reinterpret_cast<v4f*>(p) = v;
   };
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #undef FUSED_DMA_PIECE
 }
 
-#define FUSED_OPT 883       // production scheduling options (OPT bits 0, 1, 4, 5, 6, 8, 9 of the kernel)
+#define FUSED_OPT 1907       // production scheduling options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10 of the kernel)
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
 template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0, int OPT = 0>
@@ -738,6 +742,7 @@ hipError_t launch_fused_opt(A... args) {
     case 0: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 0>(args...);
     case 115: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 115>(args...);      // (A/B: e stream by 64-bit lane addresses)
     case 371: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 371>(args...);      // (A/B: no raised issue priority)
+    case 883: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 883>(args...);      // (A/B: GEMM 1 slabs of e non-temporal too)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 }
