@@ -1,7 +1,19 @@
 #!/bin/bash
-# issue priority (s_setprio) outside the GEMM phases: bit 9 gathers..LayerNorms, bit 10 prologue, bit 11 output phases
+# OPT bit 11 (B h[i] once per uniform tile): parity, then A/B against production
 mkdir -p gpurun_out/p
-for opt in 371 883 1907 2931 3955 371 883 1907 2931 3955; do
+timeout 400 python - > gpurun_out/p/parity.log 2>&1 <<PY
+import torch; torch.zeros(1, device="cuda")
+from difusco_amd import _lib
+_lib.check(_lib.lib().difusco_debug_set(7, 3955))
+import pytest, sys
+sys.exit(pytest.main(["tests/test_gpu_parity.py", "-q", "-x", "-m", "gpu", "-k", "test_edge_layer_fused or golden_h256 or tsp1000_oracle or tsp500_x16", "-p", "no:cacheprovider"]))
+PY
+echo "parity 3955: $(tail -1 gpurun_out/p/parity.log)"
+for opt in 1907 3955 1907 3955; do
   timeout 300 python bench.py --steps 30 --warmup 5 --no-exact-fp32 --cpu-steps 0 --fused-opt $opt 2>/dev/null | grep '^{' > gpurun_out/p/bench_$opt.json
   python -c "import json; r=json.load(open('gpurun_out/p/bench_$opt.json')); print($opt, r['value'], r['ms_per_step'], r['roofline']['frac'])"
+done
+for opt in 1907 3955; do
+  timeout 300 python bench.py --workload mis --steps 10 --warmup 2 --no-exact-fp32 --cpu-steps 0 --fused-opt $opt 2>/dev/null | grep '^{' > gpurun_out/p/bench_mis_$opt.json
+  python -c "import json; r=json.load(open('gpurun_out/p/bench_mis_$opt.json')); print('mis', $opt, r['value'], r['ms_per_step'])"
 done
