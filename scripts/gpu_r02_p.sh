@@ -1,5 +1,5 @@
 #!/bin/bash
-# OPT bit 11 (B h[i] once per uniform tile): parity, then A/B against production
+# OPT bit 11 (L2 touch of the next tile): parity, then A/B against production
 mkdir -p gpurun_out/p
 timeout 400 python - > gpurun_out/p/parity.log 2>&1 <<PY
 import torch; torch.zeros(1, device="cuda")
