@@ -24,6 +24,10 @@ hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS) {
     case 29: return launch_fused_t<FFp16, 16 + 196608, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);    // stamps, neither (requests still issued)
     case 30: return launch_fused_t<FFp16, 16 + 128, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);       // stamps, no B h[i] gathers
     case 31: return launch_fused_t<FFp16, 16 + 256, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS);       // stamps, no A h[j] / V h[j] gathers
+    case 32:      // stamps, LAST layer of a TSP step (no V gathers / gate / neighbour sum; GroupNorm partial sums go to `part`)
+      return launch_fused_t<FFp16, 16, FUSED_NW, false, true, 1, FUSED_OPT>(ABL_ARGS, nullptr, nullptr, nullptr, part);
+    case 33:      // stamps, FIRST layer (two-row table instead of e and GEMM 1; the table rows are taken from b_c .. for timing only)
+      return launch_fused_t<FFp16, 16, FUSED_NW, true, false, 0, FUSED_OPT>(ABL_ARGS, node4, nullptr, nullptr, nullptr);
     default: return hipErrorInvalidValue;
   }
 #undef ABL_ARGS

@@ -684,14 +684,28 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           }
         }
     }
-    if constexpr (GNP) {     // all lanes again: 16 wave sums, lane 0 writes the quarter's 8 (sum, sum of squares) pairs
+    if constexpr (GNP) {
+      // all lanes again: the quarter's 16 per-lane partials (8 sums, 8 sums of squares) are summed over the 64 lanes through
+      // the wave's aggregation scratch (unused by this variant): 16 writes, 16 reads and two shuffles per lane instead of
+      // sixteen 6-step butterflies - those cost 4.7 k cycles per quarter, 16 % of the kernel (phase stamps, study notes section 8)
+      static_assert(TAIL == 1, "the GroupNorm sums reuse the neighbour-sum scratch");
+      static_assert(32 * SCR_STRIDE >= 64 * 17, "scratch too small for the 64 x 16 partials");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wave_sum2(gs[u], gq[u]);
-      if (lane == 0) {
-#pragma unroll
-        for (int u = 0; u < 8; u += 2)
-          *reinterpret_cast<v4f*>(gn_tile + (long long)tile * 64 + qt * 16 + 2 * u) = v4f{gs[u], gq[u], gs[u + 1], gq[u + 1]};
+      for (int u = 0; u < 8; ++u) {
+        scr[lane * 17 + u] = gs[u];
+        scr[lane * 17 + 8 + u] = gq[u];
       }
+      __builtin_amdgcn_wave_barrier();
+      const int gv = lane & 15, g4 = lane >> 4;      // lane sums value gv over lanes 16 g4 .. 16 g4 + 15
+      float tot = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += scr[(g4 * 16 + k) * 17 + gv];
+      tot += __shfl_xor(tot, 16, 64);
+      tot += __shfl_xor(tot, 32, 64);
+      __builtin_amdgcn_wave_barrier();
+      // gn_tile[tile][8 qt + u][sum, sum of squares]
+      if (lane < 16) gn_tile[(long long)tile * 64 + qt * 16 + 2 * (gv & 7) + (gv >> 3)] = tot;
     }
     if (qt == 0) { FUSED_STAMP(8) }
   }
