@@ -18,8 +18,9 @@ struct FBf16 {
   __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
     v2f f = {a, b};
     v2bf h = __builtin_convertvector(f, v2bf);
-    a -= (float)h[0];
-    b -= (float)h[1];
+    f = f - __builtin_convertvector(h, v2f);      // (one packed subtract for the pair)
+    a = f[0];
+    b = f[1];
     return __builtin_bit_cast(unsigned, h);
   }
   __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
@@ -31,8 +32,9 @@ struct FFp16 {
   __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
     v2f f = {a, b};
     v2h h = __builtin_convertvector(f, v2h);
-    a -= (float)h[0];
-    b -= (float)h[1];
+    f = f - __builtin_convertvector(h, v2f);      // (one packed subtract for the pair)
+    a = f[0];
+    b = f[1];
     return __builtin_bit_cast(unsigned, h);
   }
   __device__ static __forceinline__ v16f mfma(frag a, frag b, v16f c) {
@@ -57,6 +59,16 @@ __device__ __forceinline__ void split8(const float (&x)[8], typename T::frag& hi
 
 // LDS element offset of (entry, half) inside a plane: 32-byte rows, halves swapped on odd 8-row groups
 __device__ __forceinline__ int wslot(int entry, int half) { return entry * 16 + ((half ^ ((entry >> 3) & 1)) << 3); }
+
+// the same on a register pair: the multiply and the add are packed (v_pk_mul_f32, v_pk_add_f32); element for element the
+// arithmetic of fast_sigmoid
+__device__ __forceinline__ v2f fast_sigmoid2(v2f x) {
+  v2f t = x * v2f{-1.4426950408889634f, -1.4426950408889634f};
+  t = v2f{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  t = v2f{1.0f, 1.0f} + t;
+  return v2f{__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+}
+#define DIFUSCO_PAIR(v, i) (v2f{(v)[(i)], (v)[(i) + 1]})
 
 // sigmoid on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each)
 __device__ __forceinline__ float fast_sigmoid(float x) {

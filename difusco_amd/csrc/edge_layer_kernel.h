@@ -113,10 +113,12 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //   bit 5  two stages of cover for the e stream (kDeepE below);  bit 6  LayerNorm reductions as four partial sums (kPart).
   //   bit 8  GEMM 1 input slabs of e through a buffer resource (kBufRing below).
   //   bit 9  raised issue priority outside the GEMM phases;  bit 10  default cache policy for the GEMM 1 slabs of e.
-  // Production = 1907 (bits 0, 1, 4, 5, 6, 8, 9, 10): +14 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
+  //   bit 11 element-wise arithmetic on register pairs (kPk below).
+  // Production = 3955 (bits 0, 1, 4, 5, 6, 8, 9, 10, 11): +16 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
   // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5, 8-10 do not change a result bit; bit 6
-  // changes the summation order of the LayerNorm statistics (fp32 rounding, ~1e-6 on e).
+  // changes the summation order of the LayerNorm statistics and bit 11 where the compiler contracts multiply-adds (fp32
+  // rounding, ~1e-6 on e; 9 % of the elements move by one or two ulps between 1907 and 3955).
   // ABL: profiling-only ablation mask, 0 in production (bit0 no gathers, bit1 no neighbour sum,
   // bit2 no LN/activation math, bit3 no GEMM 2); compile-time so that it cannot perturb the real kernel
   constexpr int ablate = ABL;
@@ -421,7 +423,14 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // OPT bit 6: the four LayerNorm reductions (sum, centred sum of squares, twice) run as FOUR interleaved partial sums per
   // lane instead of one 128-term serial chain each; same terms, different summation order (fp32 rounding only)
   constexpr bool kPart = (OPT & 64) != 0;
+  // OPT bit 11: the element-wise arithmetic of the gate, the two LayerNorms and the activation is written on register PAIRS
+  // (elements 2p, 2p+1 of an accumulator tuple, .xy / .zw of the parameter vectors) so that it maps to v_pk_add / v_pk_mul /
+  // v_pk_fma_f32 without the v_mov pairs hipcc's own vectoriser needed for the pairs it chose; element for element the same
+  // operations in the same order as the scalar code (requires bit 6: the partial sums are the pairs' running sums)
+  constexpr bool kPk = (OPT & 2048) != 0;
+  static_assert(!kPk || kPart, "OPT bit 11 needs bit 6");
   float s1 = 0.0f, s1p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  v2f s1k[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
   // segment structure of the tile: bit k of bnd = edge k starts a new centre node (wave uniform)
   const int i_prev = __shfl_up(i_node, 1, 64);
   const unsigned bnd = (unsigned)__ballot(l31 > 0 && i_node != i_prev);
@@ -462,6 +471,22 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
       const v4f ah = ga[b & 1][q2][0], bh = ga[b & 1][q2][1], vh = ga[b & 1][q2][2];
       v4f m;
+      if constexpr (kPk) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int r = 4 * g + 2 * h2;
+          const v2f ce = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(bc, 2 * h2);
+          const v2f ev = (DIFUSCO_PAIR(ah, 2 * h2) + DIFUSCO_PAIR(bh, 2 * h2)) + ce;
+          acc1[nb][r] = ev[0];
+          acc1[nb][r + 1] = ev[1];
+          s1k[h2] += ev;
+          if constexpr (TAIL != 1) {
+            const v2f sg = fast_sigmoid2(ev) * DIFUSCO_PAIR(vh, 2 * h2);
+            m[2 * h2] = valid ? sg[0] : 0.0f;
+            m[2 * h2 + 1] = valid ? sg[1] : 0.0f;
+          }
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float ce = acc1[nb][4 * g + q] + bc[q];
@@ -469,6 +494,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
         acc1[nb][4 * g + q] = ev;
         if constexpr (kPart) s1p[q] += ev; else s1 += ev;
         if constexpr (TAIL != 1) m[q] = valid ? fast_sigmoid(ev) * vh[q] : 0.0f;   // (select: pad lanes may hold anything)
+      }
       }
       if constexpr (TAIL != 1) *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
     }
@@ -514,9 +540,24 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
   constexpr float inv_h = 1.0f / 256.0f;
   constexpr bool skip_math = (ablate & 4) != 0;
-  if constexpr (kPart) s1 = (s1p[0] + s1p[1]) + (s1p[2] + s1p[3]);
+  if constexpr (kPk) s1 = (s1k[0][0] + s1k[0][1]) + (s1k[1][0] + s1k[1][1]);
+  else if constexpr (kPart) s1 = (s1p[0] + s1p[1]) + (s1p[2] + s1p[3]);
   const float mean1 = skip_math ? 0.0f : (s1 + __shfl_xor(s1, 32, 64)) * inv_h;
   float q1 = 0.0f, q1p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (kPk) {
+    v2f qk[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
+    const v2f mean1k = {mean1, mean1};
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const v2f d = DIFUSCO_PAIR(acc1[nb], 2 * pr) - mean1k;
+        acc1[nb][2 * pr] = d[0];
+        acc1[nb][2 * pr + 1] = d[1];
+        qk[pr & 1] += d * d;
+      }
+    q1 = (qk[0][0] + qk[0][1]) + (qk[1][0] + qk[1][1]);
+  } else {
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
@@ -526,8 +567,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       if constexpr (kPart) q1p[r & 3] += d * d; else q1 += d * d;
     }
   if constexpr (kPart) q1 = (q1p[0] + q1p[1]) + (q1p[2] + q1p[3]);
+  }
   const float rstd1 = __builtin_amdgcn_rsqf((q1 + __shfl_xor(q1, 32, 64)) * inv_h + 1e-5f);
   float s2 = 0.0f, s2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  v2f s2k[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
   if constexpr (!skip_math) {
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
@@ -537,6 +580,17 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
         const v4f ge = *reinterpret_cast<const v4f*>(prm + P_GE * H + fb);
         const v4f be = *reinterpret_cast<const v4f*>(prm + P_BE * H + fb);
         const v4f tb = *reinterpret_cast<const v4f*>(prm + P_T * H + fb);
+        if constexpr (kPk) {
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int r = 4 * g + 2 * h2;
+            v2f y = DIFUSCO_PAIR(acc1[nb], r) * v2f{rstd1, rstd1} * DIFUSCO_PAIR(ge, 2 * h2) + DIFUSCO_PAIR(be, 2 * h2);
+            y = v2f{y[0] > 0.0f ? y[0] : 0.0f, y[1] > 0.0f ? y[1] : 0.0f} + DIFUSCO_PAIR(tb, 2 * h2);
+            acc1[nb][r] = y[0];
+            acc1[nb][r + 1] = y[1];
+            s2k[h2] += y;
+          }
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float y = acc1[nb][4 * g + q] * rstd1 * ge[q] + be[q];
@@ -544,11 +598,27 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           acc1[nb][4 * g + q] = y;
           if constexpr (kPart) s2p[q] += y; else s2 += y;
         }
+        }
       }
   }
-  if constexpr (kPart) s2 = (s2p[0] + s2p[1]) + (s2p[2] + s2p[3]);
+  if constexpr (kPk) s2 = (s2k[0][0] + s2k[0][1]) + (s2k[1][0] + s2k[1][1]);
+  else if constexpr (kPart) s2 = (s2p[0] + s2p[1]) + (s2p[2] + s2p[3]);
   const float mean2 = (s2 + __shfl_xor(s2, 32, 64)) * inv_h;
   float q2s = 0.0f, q2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if constexpr (kPk) {
+    v2f qk[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
+    const v2f mean2k = {mean2, mean2};
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int pr = 0; pr < 8; ++pr) {
+        const v2f d = DIFUSCO_PAIR(acc1[nb], 2 * pr) - mean2k;
+        acc1[nb][2 * pr] = d[0];
+        acc1[nb][2 * pr + 1] = d[1];
+        qk[pr & 1] += d * d;
+      }
+    q2s = (qk[0][0] + qk[0][1]) + (qk[1][0] + qk[1][1]);
+  } else {
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
@@ -558,6 +628,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       if constexpr (kPart) q2p[r & 3] += d * d; else q2s += d * d;
     }
   if constexpr (kPart) q2s = (q2p[0] + q2p[1]) + (q2p[2] + q2p[3]);
+  }
   const float rstd2 = __builtin_amdgcn_rsqf((q2s + __shfl_xor(q2s, 32, 64)) * inv_h + 1e-5f);
 
   // activation -> 16-bit planes, kept in registers as the B operands of GEMM 2
@@ -573,10 +644,20 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
         const int fb = 32 * nb + 8 * g + 4 * hh;
         const v4f go = *reinterpret_cast<const v4f*>(prm + P_GO * H + fb);
         const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BO * H + fb);
+        if constexpr (kPk && !skip_math) {
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const v2f z = DIFUSCO_PAIR(acc1[nb], 4 * g + 2 * h2) * v2f{rstd2, rstd2} * DIFUSCO_PAIR(go, 2 * h2) + DIFUSCO_PAIR(bo, 2 * h2);
+            const v2f a = z * fast_sigmoid2(z);
+            a8[4 * g2 + 2 * h2] = a[0];
+            a8[4 * g2 + 2 * h2 + 1] = a[1];
+          }
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float z = acc1[nb][4 * g + q] * rstd2 * go[q] + bo[q];
           a8[4 * g2 + q] = skip_math ? z : z * fast_sigmoid(z);
+        }
         }
       }
       split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
@@ -675,8 +756,17 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           const int fo = 64 * qt + 32 * nbp + 8 * g + 4 * hh;
           const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BOUT * H + fo);
           v4f v;
+          if constexpr (kPk) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const v2f o = DIFUSCO_PAIR(ein[nbp][g], 2 * h2) + (DIFUSCO_PAIR(acc2[nbp], 4 * g + 2 * h2) + DIFUSCO_PAIR(bo, 2 * h2));
+              v[2 * h2] = o[0];
+              v[2 * h2 + 1] = o[1];
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
+          }
           st_e(((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256), v);
           if constexpr (GNP) {
             gs[nbp * 4 + g] = (v[0] + v[1]) + (v[2] + v[3]);
@@ -723,7 +813,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #undef FUSED_DMA_PIECE
 }
 
-#define FUSED_OPT 1907       // production scheduling options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10 of the kernel)
+#define FUSED_OPT 3955       // production scheduling options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10, 11 of the kernel)
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
 template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0, int OPT = 0>
@@ -757,6 +847,7 @@ hipError_t launch_fused_opt(A... args) {
     case 115: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 115>(args...);      // (A/B: e stream by 64-bit lane addresses)
     case 371: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 371>(args...);      // (A/B: no raised issue priority)
     case 883: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 883>(args...);      // (A/B: GEMM 1 slabs of e non-temporal too)
+    case 1907: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 1907>(args...);    // (A/B: scalar element-wise arithmetic)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 }

@@ -2,7 +2,7 @@
 # production = iterative-maxocc scheduler + OPT 371: full GPU suite, default bench first (fresh box), then profiles, workloads
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/o4; mkdir -p $O
+O=gpurun_out/o5; mkdir -p $O
 timeout 600 python bench.py 2> $O/bench_default.err | grep '^{' > $O/bench_default.json; cut -c1-400 $O/bench_default.json
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
