@@ -5,7 +5,7 @@ import os
 
 from .build import LIB_PATH
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
@@ -86,6 +86,7 @@ def lib():
     L.difusco_tsp_merge_workspace_bytes.argtypes = [i64, ctypes.POINTER(ctypes.c_size_t)]
     L.difusco_tsp_merge_tour.argtypes = [i32, i64, vp, vp, f32p, f32p, vp, ctypes.c_size_t, vp,
                                          ctypes.POINTER(i64), ctypes.POINTER(i32), vp]
+    L.difusco_tsp_merge_tours.argtypes = [i32, i64, vp, vp, f32p, f32p, i32, vp, ctypes.c_size_t, vp, vp, vp, vp]
     L.difusco_tsp_two_opt_workspace_bytes.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_size_t)]
     L.difusco_tsp_two_opt.argtypes = [i32, i32, vp, vp, i64, vp, ctypes.c_size_t, ctypes.POINTER(i64), vp]
     L.difusco_knn_graph_workspace_bytes.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_size_t)]

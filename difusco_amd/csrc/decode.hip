@@ -136,6 +136,9 @@ int find_root(std::vector<int>& link, int i) {
   return r;
 }
 
+int merge_one_sample(const Carve& c, int n_nodes, long long E, const float* heat, const float* points, hipStream_t st,
+                     int32_t* tour_out, int64_t* merge_iterations, int32_t* completed);
+
 }  // namespace
 }  // namespace difusco
 
@@ -150,19 +153,21 @@ int difusco_tsp_merge_workspace_bytes(int64_t n_edges, size_t* bytes) {
   return DIFUSCO_OK;
 }
 
-int difusco_tsp_merge_tour(int n_nodes, int64_t n_edges, const int32_t* row, const int32_t* col, const float* heat,
-                           const float* points, void* workspace, size_t workspace_bytes, int32_t* tour_out,
-                           int64_t* merge_iterations, int32_t* completed, void* stream) {
+// samples: heat [n_samples][n_edges], tour_out [n_samples][n_nodes + 1], merge_iterations / completed [n_samples] (optional).
+// The pair keys depend on the graph only: one key sort serves every sample of the call.
+static int merge_tours_impl(const char* who, int n_nodes, int64_t n_edges, const int32_t* row, const int32_t* col,
+                            const float* heat, const float* points, int n_samples, void* workspace, size_t workspace_bytes,
+                            int32_t* tour_out, int64_t* merge_iterations, int32_t* completed, void* stream) {
   using namespace difusco;
-  if (n_nodes < 3 || n_edges <= 0 || !row || !col || !heat || !points || !workspace || !tour_out)
-    return set_error(DIFUSCO_EINVAL, "tsp_merge_tour: needs n_nodes >= 3, n_edges > 0 and non-null arrays");
-  if (n_edges > 0xffffffffLL) return set_error(DIFUSCO_EINVAL, "tsp_merge_tour: more than 2^32 edges in one graph");
+  if (n_nodes < 3 || n_edges <= 0 || n_samples < 1 || !row || !col || !heat || !points || !workspace || !tour_out)
+    return set_error(DIFUSCO_EINVAL, "%s: needs n_nodes >= 3, n_edges > 0, n_samples >= 1 and non-null arrays", who);
+  if (n_edges > 0xffffffffLL) return set_error(DIFUSCO_EINVAL, "%s: more than 2^32 edges in one graph", who);
   const long long E = n_edges, N = n_nodes;
   Carve c;
   hipError_t er = carve(workspace, E, &c);
   if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "rocprim temp size: %s", hipGetErrorString(er));
   if (workspace_bytes < c.total)
-    return set_error(DIFUSCO_EINVAL, "tsp_merge_tour: workspace %zu < %zu bytes", workspace_bytes, c.total);
+    return set_error(DIFUSCO_EINVAL, "%s: workspace %zu < %zu bytes", who, workspace_bytes, c.total);
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((E + 255) / 256);
   int key_bits = 1;
@@ -172,7 +177,39 @@ int difusco_tsp_merge_tour(int n_nodes, int64_t n_edges, const int32_t* row, con
   size_t tb = c.temp_bytes;
   er = rocprim::radix_sort_pairs(c.temp, tb, c.key_a, c.key_b, c.val_a, c.val_b, (size_t)E, 0, key_bits, st, false);
   if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "radix_sort_pairs: %s", hipGetErrorString(er));
-  er = hipMemsetAsync(c.counters, 0, 256, st);
+  for (int smp = 0; smp < n_samples; ++smp) {
+    const int rc = merge_one_sample(c, n_nodes, E, heat + (long long)smp * E, points, st, tour_out + (long long)smp * (N + 1),
+                                    merge_iterations ? merge_iterations + smp : nullptr, completed ? completed + smp : nullptr);
+    if (rc != DIFUSCO_OK) return rc;
+  }
+  return DIFUSCO_OK;
+}
+
+int difusco_tsp_merge_tour(int n_nodes, int64_t n_edges, const int32_t* row, const int32_t* col, const float* heat,
+                           const float* points, void* workspace, size_t workspace_bytes, int32_t* tour_out,
+                           int64_t* merge_iterations, int32_t* completed, void* stream) {
+  return merge_tours_impl("tsp_merge_tour", n_nodes, n_edges, row, col, heat, points, 1, workspace, workspace_bytes, tour_out,
+                          merge_iterations, completed, stream);
+}
+
+int difusco_tsp_merge_tours(int n_nodes, int64_t n_edges, const int32_t* row, const int32_t* col, const float* heat,
+                            const float* points, int n_samples, void* workspace, size_t workspace_bytes, int32_t* tours_out,
+                            int64_t* merge_iterations, int32_t* completed, void* stream) {
+  return merge_tours_impl("tsp_merge_tours", n_nodes, n_edges, row, col, heat, points, n_samples, workspace, workspace_bytes,
+                          tours_out, merge_iterations, completed, stream);
+}
+
+}  // extern "C"
+
+namespace difusco {
+namespace {
+// steps 2-4 of the header comment for ONE sample; c.key_b / c.val_b hold the pair-sorted edge list of the graph
+int merge_one_sample(const Carve& c, int n_nodes, long long E, const float* heat, const float* points, hipStream_t st,
+                     int32_t* tour_out, int64_t* merge_iterations, int32_t* completed) {
+  const long long N = n_nodes;
+  const unsigned grid = (unsigned)((E + 255) / 256);
+  size_t tb = c.temp_bytes;
+  hipError_t er = hipMemsetAsync(c.counters, 0, 256, st);
   if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "memset: %s", hipGetErrorString(er));
   hipLaunchKernelGGL(pair_score_kernel, dim3(grid), dim3(256), 0, st, c.key_b, c.val_b, heat, points, E, N, c.score_a,
                      c.pair_a, c.counters);
@@ -286,5 +323,5 @@ int difusco_tsp_merge_tour(int n_nodes, int64_t n_edges, const int32_t* row, con
   if (completed) *completed = within;
   return DIFUSCO_OK;
 }
-
-}  // extern "C"
+}  // namespace
+}  // namespace difusco

@@ -3,7 +3,7 @@
 
 Same signature and return value as the reference function: ``(tours, merge_iterations)`` with one closed tour
 (list starting and ending at node 0) per parallel sample and the mean of the per-sample iteration counters.  The
-work goes through ``difusco_tsp_merge_tour`` of libdifusco_hip.so (pair keys, scores and the two sorts on the GPU,
+work goes through ``difusco_tsp_merge_tours`` of libdifusco_hip.so (pair keys, scores and the two sorts on the GPU,
 the reference's route bookkeeping on the host); there is no CPU fallback.  Keyword-only extensions: ``device``,
 ``return_completed`` (adds the per-sample flag that says whether the tour was assembled from positive-score
 candidate pairs, the regime pinned against the reference)."""
@@ -45,19 +45,19 @@ def merge_tours(adj_mat, np_points, edge_index_np, sparse_graph=False, parallel_
     _lib.check(L.difusco_tsp_merge_workspace_bytes(E, ctypes.byref(nbytes)))
     ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    tours, iters, done = [], [], []
     row, col = ei[0].contiguous(), ei[1].contiguous()
-    for s in range(parallel_sampling):
-        tour = np.empty(n + 1, dtype=np.int32)
-        it, ok = ctypes.c_int64(), ctypes.c_int32()
-        _lib.check(L.difusco_tsp_merge_tour(n, E, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()),
-                                            ctypes.c_void_p(heat[s].data_ptr()), ctypes.c_void_p(pts.data_ptr()),
-                                            ctypes.c_void_p(ws.data_ptr()), nbytes.value,
-                                            tour.ctypes.data_as(ctypes.c_void_p), ctypes.byref(it), ctypes.byref(ok),
-                                            stream))
-        tours.append(tour.tolist())
-        iters.append(it.value)
-        done.append(bool(ok.value))
+    # one C call for all samples of the graph (the pair-key sort is shared; the per-sample loop of tsp_utils.py:100-145 runs
+    # inside the library)
+    tours_np = np.empty((parallel_sampling, n + 1), dtype=np.int32)
+    iters = np.zeros(parallel_sampling, dtype=np.int64)
+    done_np = np.zeros(parallel_sampling, dtype=np.int32)
+    _lib.check(L.difusco_tsp_merge_tours(n, E, ctypes.c_void_p(row.data_ptr()), ctypes.c_void_p(col.data_ptr()),
+                                         ctypes.c_void_p(heat.data_ptr()), ctypes.c_void_p(pts.data_ptr()), parallel_sampling,
+                                         ctypes.c_void_p(ws.data_ptr()), nbytes.value,
+                                         tours_np.ctypes.data_as(ctypes.c_void_p), iters.ctypes.data_as(ctypes.c_void_p),
+                                         done_np.ctypes.data_as(ctypes.c_void_p), stream))
+    tours = [t.tolist() for t in tours_np]
+    done = [bool(v) for v in done_np]
     merge_iterations = float(np.mean(iters))
     return (tours, merge_iterations, done) if return_completed else (tours, merge_iterations)
 

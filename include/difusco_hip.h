@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 6
+#define DIFUSCO_ABI_VERSION 7
 
 enum {
   DIFUSCO_OK = 0,
@@ -251,6 +251,13 @@ int difusco_tsp_merge_workspace_bytes(int64_t n_edges, size_t* bytes);
 int difusco_tsp_merge_tour(int n_nodes, int64_t n_edges, const int32_t* row, const int32_t* col, const float* heat,
                            const float* points, void* workspace, size_t workspace_bytes, int32_t* tour_out,
                            int64_t* merge_iterations, int32_t* completed, void* stream);
+/* The `parallel_sampling` samples of ONE graph in one call (the loop of tsp_utils.py:100-145 over adj_mat[i]):
+ * heat [n_samples][n_edges] DEVICE, tours_out [n_samples][n_nodes + 1] HOST, merge_iterations / completed [n_samples]
+ * HOST (optional).  The pair keys depend on the graph only, so their sort runs once per call; the workspace is the
+ * one of difusco_tsp_merge_workspace_bytes.  Results per sample equal difusco_tsp_merge_tour's. */
+int difusco_tsp_merge_tours(int n_nodes, int64_t n_edges, const int32_t* row, const int32_t* col, const float* heat,
+                            const float* points, int n_samples, void* workspace, size_t workspace_bytes,
+                            int32_t* tours_out, int64_t* merge_iterations, int32_t* completed, void* stream);
 
 /* ---- batched 2-opt: difusco/utils/tsp_utils.py:12-49 (batched_two_opt_torch).  points: DEVICE
  * float64 [n_nodes,2]; tours: DEVICE int32 [batch, n_nodes+1] closed tours, refined in place.  Every iteration

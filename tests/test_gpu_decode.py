@@ -78,6 +78,40 @@ def test_merge_tours_matches_oracle(dev, n, k, kind, shuffle):
         assert it == ref_it
 
 
+def test_merge_tours_batch_entry_equals_per_sample_entry(dev):
+    """difusco_tsp_merge_tours (one key sort for all samples of a graph, what decode.merge_tours calls) against
+    difusco_tsp_merge_tour called sample by sample: tours, iteration counters and completion flags are equal."""
+    import ctypes
+    import torch
+    from difusco_amd import _lib
+    from difusco_amd.decode import merge_tours
+    from difusco_amd.synthetic import tsp_instance
+    rng = np.random.default_rng(7)
+    n, k, par = 300, 30, 5
+    pts, ei = tsp_instance(n, k, seed=3)
+    heat = np.stack([_heat(kind, pts, ei, rng) for kind in ("bits", "prob", "gauss", "bits", "prob")])
+    tours, it_mean, done = merge_tours(heat, pts, ei, sparse_graph=True, parallel_sampling=par, device=dev,
+                                       return_completed=True)
+    L = _lib.lib()
+    d = lambda a, t: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=t)
+    row, col, p32 = d(ei[0], torch.int32), d(ei[1], torch.int32), d(pts, torch.float32)
+    nbytes = ctypes.c_size_t()
+    _lib.check(L.difusco_tsp_merge_workspace_bytes(ei.shape[1], ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    its = []
+    for smp in range(par):
+        h = d(heat[smp], torch.float32)
+        tour = np.empty(n + 1, dtype=np.int32)
+        it, ok = ctypes.c_int64(), ctypes.c_int32()
+        _lib.check(L.difusco_tsp_merge_tour(n, ei.shape[1], row.data_ptr(), col.data_ptr(), ctypes.c_void_p(h.data_ptr()),
+                                            ctypes.c_void_p(p32.data_ptr()), ws.data_ptr(), nbytes.value,
+                                            tour.ctypes.data_as(ctypes.c_void_p), ctypes.byref(it), ctypes.byref(ok), None))
+        assert tour.tolist() == tours[smp] and bool(ok.value) == done[smp]
+        its.append(it.value)
+    assert it_mean == float(np.mean(its))
+    assert sorted(tours[0][:-1]) == list(range(n)) and tours[0][0] == tours[0][-1] == 0
+
+
 def test_merge_tours_full_size_properties(dev):
     """TSP-10000 / K=100 (10^6 heat entries; the reference would sort 10^8): a valid closed tour, bitwise
     deterministic, invariant under a permutation of the edge list, and made of candidate edges wherever the

@@ -318,6 +318,8 @@ def test_decode_entry_points_reject_bad_arguments_without_gpu():
     assert L.difusco_tsp_merge_tour(2, 10, p, p, p, p, p, 1 << 20, p, ctypes.byref(it), ctypes.byref(ok), None) < 0
     assert "n_nodes >= 3" in L.difusco_last_error().decode()
     assert L.difusco_tsp_merge_tour(10, 10, p, None, p, p, p, 1 << 20, p, ctypes.byref(it), ctypes.byref(ok), None) < 0
+    assert L.difusco_tsp_merge_tours(10, 10, p, p, p, p, 0, p, 1 << 20, p, None, None, None) < 0      # no samples
+    assert "n_samples" in L.difusco_last_error().decode()
     assert L.difusco_tsp_two_opt_workspace_bytes(3, 1, ctypes.byref(nbytes)) < 0
     assert L.difusco_tsp_two_opt(3, 1, p, p, 10, p, 1 << 20, ctypes.byref(it), None) < 0
     assert L.difusco_tsp_two_opt_workspace_bytes(1000, 4, ctypes.byref(nbytes)) == 0 and nbytes.value > 4 * 1001 * 16
