@@ -54,6 +54,9 @@ struct Layout {
   int64_t layer_stride = 0;  // floats between the same tensor of consecutive layers
 };
 
+// hipMemsetAsync of zero bytes is an error while a stream is being captured into a hipGraph
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st) { return bytes ? hipMemsetAsync(p, 0, bytes, st) : hipSuccess; }
+
 bool hidden_ok(int h) { return h == 64 || h == 128 || h == 256; }
 
 Layout make_layout(int H, int L, int C) {
@@ -304,7 +307,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
     PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
                                        H, H, H, st))
     if (fused)   // pad lanes of the last tiles must read as zero in every later kernel
-      PROF(PROF_EMBED, hipMemsetAsync(ws.e + (E / 32) * 32 * H, 0, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
+      PROF(PROF_EMBED, zero_async(ws.e + (E / 32) * 32 * H, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
     if (a->xt_is_binary) {
       PROF(PROF_EMBED, launch_scalar_embed(nullptr, nullptr, G(DIFUSCO_W_DIMT_SCALAR), 2, H, ws.table_in, st))
       PROF(PROF_EMBED, launch_two_rows_linear(H, ws.table_in, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), ws.table,
@@ -332,7 +335,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                        H, H, H, st))
     if (l0_fold) {   // e = zeros (gnn_encoder.py:407) comes from an all-zero table; only the pad tail must read as zero
       PROF(PROF_EMBED, hipMemsetAsync(ws.table, 0, sizeof(float) * 4 * H, st))
-      PROF(PROF_EMBED, hipMemsetAsync(ws.e + (E / 32) * 32 * H, 0, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
+      PROF(PROF_EMBED, zero_async(ws.e + (E / 32) * 32 * H, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
     } else if (E > 0) {
       PROF(PROF_EMBED, hipMemsetAsync(ws.e, 0, sizeof(float) * (fused ? E_pad : E) * H, st))
     }
