@@ -1017,3 +1017,31 @@ def test_torch_custom_ops_equal_ctypes_path(dev, fused):
     for key in ("cat", "philox", "two_phase", "gau", "mis"):
         for a, b in zip(res["ctypes", key], res["torch", key]):
             assert torch.equal(a, b), key
+
+
+def test_denoise_step_is_graph_capturable(dev):
+    """A whole step (default engine, TSP categorical, H=256) captured into a hipGraph through torch.cuda.CUDAGraph and
+    replayed gives the bits of the direct call: every launch goes to the caller's stream and nothing in the library
+    synchronises, allocates or issues an operation that stream capture rejects."""
+    from difusco_amd import TSPModel
+    H, Lyr = 256, 3
+    p = O.init_params(H, Lyr, 2, seed=131)
+    pts, ei = O.tsp_instance(96, 12, seed=14)          # E = 1152 edges: not a multiple of 256, so the pad memset is non-empty
+    pts, ei = torch.from_numpy(pts).to(dev), torch.from_numpy(ei).to(dev)
+    m = TSPModel(_args("categorical", 12, H=H, L=Lyr), p, device=dev)
+    g = torch.Generator().manual_seed(5)
+    u = torch.rand(ei.shape[1], generator=g).to(dev)      # (a host tensor would be copied inside the capture: not capturable)
+    x0 = (torch.randn(ei.shape[1], generator=g) > 0).float().to(dev)
+    step = lambda x: m.categorical_denoise_step(pts, x, np.array([700]), dev, ei, target_t=np.array([650]), uniform=u,
+                                                return_aux=True)
+    x1, _, _ = step(x0)                                # x1 is the model's own output: known binary without a device check
+    torch.cuda.synchronize()
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(graph, stream=side):
+        out, logits, prob = step(x1)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    ref_out, ref_logits, ref_prob = step(x1)           # (direct call; x1 is checked on the device this time)
+    assert torch.equal(logits, ref_logits) and torch.equal(prob, ref_prob) and torch.equal(out, ref_out)
