@@ -102,7 +102,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // either: with only two distinct input rows, C e_in is one of two vectors (l0_table rows 2, 3 = C applied to rows 0,
   // 1, computed once per step by an exact fp32 linear on two rows); the accumulators start from that row, the
   // residual comes from the input row, and the separate embedding pass over e disappears.
-  // OPT: scheduling options that do not change any result bit (A/B through difusco_debug_set(7, ..)):
+  // OPT: scheduling / code-shape options, exact except bits 6 and 11 (see the end of this list); A/B through
+  // difusco_debug_set(7, ..):
   //   bit 0  XCD-contiguous tile ranges: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only); the
   //          remap gives every XCD one contiguous range of tiles, so that - with the nodes of a graph in Morton order
   //          (graph.py) - the neighbour-table rows A h[j], V h[j] gathered by one XCD's workgroups are a small, spatially
