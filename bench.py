@@ -184,6 +184,10 @@ def main():
                     "(difusco_debug_set key 7: 0 = all off, default = production set)")
     ap.add_argument("--node-linear-depth", type=int, default=None, choices=[1, 4],
                     help="A/B: k steps of global-load lookahead in the node-row linear (difusco_debug_set key 8)")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE",
+                    help="profiling library only: difusco_debug_set(KEY, VALUE) before the run (repeatable)")
+    ap.add_argument("--prof-lib", action="store_true", help="load libdifusco_hip_prof.so (profiling build) instead of the "
+                    "production library")
     ap.add_argument("--no-node-reorder", action="store_true", help="A/B: keep the caller's node numbering (no Morton order)")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32 (v_mfma_f32_32x32x2_f32) sub-record")
     ap.add_argument("--precision", default="fp16x3", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
@@ -229,15 +233,17 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
+    if args.fused_opt is not None or args.node_linear_depth is not None or args.prof_lib or args.debug_set:
+        os.environ["DIFUSCO_PROFILING_LIB"] = "1"      # A/B kernel variants exist in libdifusco_hip_prof.so only
     from difusco_amd import _lib
-    if args.no_l0_fold:
-        _lib.check(_lib.lib().difusco_debug_set(3, 0))
-    if args.no_gn_fold:
-        _lib.check(_lib.lib().difusco_debug_set(4, 0))
+    step_flags = (_lib.FLAG_NO_L0_FOLD if args.no_l0_fold else 0) | (_lib.FLAG_NO_TAIL_FOLD if args.no_gn_fold else 0)
     if args.fused_opt is not None:
         _lib.check(_lib.lib().difusco_debug_set(7, args.fused_opt))
     if args.node_linear_depth is not None:
         _lib.check(_lib.lib().difusco_debug_set(8, args.node_linear_depth))
+    for kv in args.debug_set:
+        k_, v_ = kv.split("=")
+        _lib.check(_lib.lib().difusco_debug_set(int(k_), int(v_)))
     from difusco_amd.dist import engine_from_broadcast, gn_allreduce, shard_range
     from difusco_amd.engine import DenoiseEngine
     from difusco_amd.models import MISModel, TSPModel
@@ -253,9 +259,10 @@ def main():
             assert (h_, l_, c_) == (H, LAYERS, 1 if gaussian else 2) and blob.numel() > 0 and bool(torch.isfinite(blob).all())
         engine = None
     elif world > 1:
-        engine = engine_from_broadcast(params, device, src=0, precision=args.precision, fused=not args.no_fusion)
+        engine = engine_from_broadcast(params, device, src=0, precision=args.precision, fused=not args.no_fusion,
+                                       flags=step_flags)
     else:
-        engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion)
+        engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion, flags=step_flags)
     margs = dict(diffusion_type=wl["diffusion"], diffusion_schedule="linear", diffusion_steps=1000,
                  inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn if not mis else -1,
                  n_layers=LAYERS, hidden_dim=H, inference_trick="ddim")
@@ -365,7 +372,7 @@ def main():
                        "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision,
                        "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3"),
                        "node_order": "caller" if (args.no_node_reorder or mis) else "morton per graph (graph.py)",
-                       "fused_opt": args.fused_opt},
+                       "fused_opt": args.fused_opt, "debug_set": args.debug_set or None},
         }
         if prof is not None and prof["launches"][0] > 0:
             n_lin = prof["launches"][0]

@@ -3,9 +3,11 @@ the import of anything that computes fails loudly (the product path never routes
 import ctypes
 import os
 
-from .build import LIB_PATH
+from .build import LIB_PATH, PROF_LIB_PATH
 
-ABI_VERSION = 7
+FLAG_NO_L0_FOLD, FLAG_NO_TAIL_FOLD = 1, 2      # difusco_step_args.flags
+
+ABI_VERSION = 8
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
@@ -22,7 +24,8 @@ W_LAYER = ["@node4.weight", "@node4.bias", "layers.{l}.C.weight", "layers.{l}.C.
            "time_embed_layers.{l}.1.weight", "time_embed_layers.{l}.1.bias",
            "per_layer_out.{l}.0.weight", "per_layer_out.{l}.0.bias",
            "per_layer_out.{l}.2.weight", "per_layer_out.{l}.2.bias",
-           "@planes:layers.{l}.C.weight", "@planes:per_layer_out.{l}.2.weight", "@planes:@node4.weight"]
+           "@planes:layers.{l}.C.weight", "@planes:per_layer_out.{l}.2.weight", "@planes:@node4.weight",
+           "@fused_scales"]
 
 
 class StepArgs(ctypes.Structure):
@@ -44,7 +47,7 @@ class StepArgs(ctypes.Structure):
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t), ("stream", ctypes.c_void_p),
         ("precision", ctypes.c_int32), ("no_fusion", ctypes.c_int32),
         ("row", ctypes.c_void_p),
-        ("gn_phase", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("gn_sums", ctypes.c_void_p),
+        ("gn_phase", ctypes.c_int32), ("flags", ctypes.c_int32), ("gn_sums", ctypes.c_void_p),
     ]
 
 
@@ -60,11 +63,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # DIFUSCO_PROFILING_LIB=1 loads the profiling build (libdifusco_hip_prof.so: the same code plus the timing-only
+    # kernel variants and their process-wide knobs, `python -m difusco_amd.build --prof`); never set in production
+    path = PROF_LIB_PATH if os.environ.get("DIFUSCO_PROFILING_LIB", "0") not in ("", "0") else LIB_PATH
+    if not os.path.exists(path):
         raise DifuscoHipError(
-            f"{LIB_PATH} is missing: build it with `python -m difusco_amd.build` "
+            f"{path} is missing: build it with `python -m difusco_amd.build` "
             "(there is deliberately no CPU / PyTorch fallback)")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     i32, i64, vp, f32p = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
     L.difusco_abi_version.restype = ctypes.c_int
     L.difusco_last_error.restype = ctypes.c_char_p
@@ -74,10 +80,10 @@ def lib():
     L.difusco_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.difusco_denoise_step.argtypes = [ctypes.POINTER(StepArgs)]
     L.difusco_linear_rows.argtypes = [f32p, f32p, f32p, f32p, f32p, i64, i32, i32, i64, vp]
-    L.difusco_linear_rows_split.argtypes = [f32p, vp, i32, f32p, f32p, f32p, i64, i32, i32, i64, vp]
+    L.difusco_linear_rows_split.argtypes = [f32p, vp, i32, f32p, f32p, f32p, i64, i32, i32, i64, f32p, vp]
     L.difusco_fused_scratch_bytes.restype = ctypes.c_size_t
     L.difusco_fused_scratch_bytes.argtypes = [i32, i32]
-    L.difusco_edge_layer_fused.argtypes = [i32, i32, i32, vp, vp, vp, f32p, f32p, f32p, vp, vp] + [f32p] * 9 + [i32, vp, vp]
+    L.difusco_edge_layer_fused.argtypes = [i32, i32, i32, vp, vp, vp, f32p, f32p, f32p, vp, vp] + [f32p] * 9 + [i32, f32p, vp, vp]
     L.difusco_edge_gate_aggregate.argtypes = [i32, i32, vp, vp, f32p, f32p, f32p] + [f32p] * 7 + [i32, vp]
     L.difusco_categorical_posterior.argtypes = [f32p, f32p, ctypes.POINTER(ctypes.c_float), i32, f32p,
                                                 ctypes.c_uint64, ctypes.c_uint64, f32p, f32p, i64, vp]

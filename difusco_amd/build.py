@@ -1,8 +1,11 @@
 """Build libdifusco_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python -m difusco_amd.build [--force]
+    python -m difusco_amd.build [--force] [--prof]
 
-The library is built IN-TREE (difusco_amd/lib/) so that it travels with a snapshot of the repo.
+The library is built IN-TREE (difusco_amd/lib/) so that it travels with a snapshot of the repo.  ``--prof`` also builds
+libdifusco_hip_prof.so: the same sources with -DDIFUSCO_PROFILING plus edge_layer_abl.hip - the timing-only kernel
+variants (ablations, phase stamps, A/B option sets) and the process-wide knobs that select them.  None of that is in
+the production library.
 """
 import os
 import subprocess
@@ -14,7 +17,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdifusco_hip.so")
-SOURCES = ["linear.hip", "linear_split.hip", "edge_layer.hip", "edge_layer_bf16.hip", "edge_layer_abl.hip", "graph_kernels.hip", "decode.hip", "two_opt.hip", "knn.hip", "mis_decode.hip", "api.hip"]
+PROF_LIB_PATH = os.path.join(LIB_DIR, "libdifusco_hip_prof.so")
+SOURCES = ["linear.hip", "linear_split.hip", "edge_layer.hip", "edge_layer_bf16.hip", "graph_kernels.hip", "decode.hip", "two_opt.hip", "knn.hip", "mis_decode.hip", "api.hip"]
+PROF_SOURCES = SOURCES + ["edge_layer_abl.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "edge_layer_common.h"), os.path.join(CSRC, "edge_layer_kernel.h"),
            os.path.join(os.path.dirname(PKG), "include", "difusco_hip.h")]
 
@@ -42,7 +47,7 @@ def build_torch_ops(force: bool = False, verbose: bool = False) -> str:
     from torch.utils import cpp_extension
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     cmd = ([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-w", TORCH_SRC, "-o", TORCH_LIB_PATH]
-           + [f"-I{p}" for p in cpp_extension.include_paths()] + ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__=1",
+           + [f"-I{p}" for p in cpp_extension.include_paths()] + [f"-I{os.path.join(rocm_root(), 'include')}", "-D__HIP_PLATFORM_AMD__=1",
               "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}", f"-L{tlib}", "-ltorch",
               "-ltorch_cpu", "-lc10", "-ltorch_hip", "-lc10_hip", f"-L{LIB_DIR}", "-ldifusco_hip", "-Wl,-rpath,$ORIGIN",
               f"-Wl,-rpath,{tlib}"])
@@ -54,23 +59,37 @@ def build_torch_ops(force: bool = False, verbose: bool = False) -> str:
     return TORCH_LIB_PATH
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _stale(lib_path, sources) -> bool:
+    if not os.path.exists(lib_path):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    t = os.path.getmtime(lib_path)
+    deps = [os.path.join(CSRC, s) for s in sources] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into one shared library; returns its path."""
-    if not force and not _stale():
-        return LIB_PATH
+def _hipcc() -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
+    return hipcc if os.path.exists(hipcc) else "hipcc"
+
+
+def rocm_root() -> str:
+    """The ROCm installation the compiler in use belongs to (ROCM_PATH, else two levels above hipcc, else /opt/rocm)."""
+    if os.environ.get("ROCM_PATH"):
+        return os.environ["ROCM_PATH"]
+    import shutil
+    exe = shutil.which(_hipcc()) or _hipcc()
+    root = os.path.dirname(os.path.dirname(os.path.realpath(exe)))
+    return root if os.path.isdir(os.path.join(root, "include")) else "/opt/rocm"
+
+
+def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str:
+    """Compile every HIP source for gfx950 into one shared library; returns its path.  prof: the profiling library."""
+    lib_path, sources = (PROF_LIB_PATH, PROF_SOURCES) if prof else (LIB_PATH, SOURCES)
+    if not force and not _stale(lib_path, sources):
+        return lib_path
+    hipcc = _hipcc()
     os.makedirs(LIB_DIR, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-DDIFUSCO_PROFILING=1"] if prof else [])
     # one hipcc per source, in parallel (the fused edge-layer files hold many template instantiations), then one link;
     # objects live in a temporary directory: only the .so stays in the tree
     with tempfile.TemporaryDirectory(prefix="difusco_build_") as tmp:
@@ -83,17 +102,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if res.returncode != 0:
                 raise RuntimeError(f"hipcc failed on {src}:\n" + res.stdout + res.stderr)
             return obj
-        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
-            objs = list(pool.map(compile_one, SOURCES))
-        cmd = [hipcc] + flags + ["-shared", "-o", LIB_PATH] + objs
+        with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 4)) as pool:
+            objs = list(pool.map(compile_one, sources))
+        cmd = [hipcc] + flags + ["-shared", "-o", lib_path] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_torch_ops(force="--force" in sys.argv, verbose=True))
+    if "--prof" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, prof=True))

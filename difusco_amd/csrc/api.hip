@@ -74,7 +74,7 @@ Layout make_layout(int H, int L, int C) {
   push(H); push(H);                       // out.0 (GroupNorm affine)
   push((int64_t)C * H); push(C);          // out.2 (1x1 conv)
   push(T2); push(T2); push(H);            // freqs, dimt_pos, dimt_scalar
-  push((int64_t)5 * H * H / 2);           // edge_embed split planes (3 bf16 + 2 fp16 planes of H*H)
+  push((int64_t)5 * H * H / 2 + H);       // edge_embed split planes (3 bf16 + 2 fp16 planes of H*H) + fp16 row inverse scales
   const int64_t layer0 = cur;
   for (int l = 0; l < L; ++l) {
     push((int64_t)4 * H * H); push((int64_t)4 * H);  // node4 = U|V|A|B
@@ -83,8 +83,9 @@ Layout make_layout(int H, int L, int C) {
     push((int64_t)H * T2); push(H);                   // time layer
     push(H); push(H);                                 // per_layer_out LN
     push((int64_t)H * H); push(H);                    // per_layer_out linear
-    push((int64_t)5 * H * H / 2); push((int64_t)5 * H * H / 2);  // split planes of C and per_layer_out
-    push((int64_t)5 * 4 * H * H / 2);                             // split planes of the node linear
+    push((int64_t)5 * H * H / 2 + H); push((int64_t)5 * H * H / 2 + H);  // split planes of C and per_layer_out (+ inverse scales)
+    push((int64_t)5 * 4 * H * H / 2 + 4 * H);                             // split planes of the node linear (+ inverse scales)
+    push(8);                                                               // operand scales of the fused edge kernel
     if (l == 0) lo.layer_stride = cur - layer0;
   }
   lo.total = cur;
@@ -92,7 +93,7 @@ Layout make_layout(int H, int L, int C) {
 }
 
 struct Workspace {
-  float *h, *node4, *e, *tmp, *tbias, *table_in, *table, *stats, *part, *direct, *gn_tile;
+  float *h, *node4, *e, *tmp, *tbias, *table_in, *table, *stats, *part, *direct, *gn_tile, *etmax, *hscale, *escale;
   double* partial;
   size_t bytes;
 };
@@ -120,6 +121,10 @@ Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk)
   w.part = (float*)take(H == 256 ? sizeof(float) * fused_part_floats(E) : 0);
   w.direct = (float*)take(H == 256 ? sizeof(float) * N * H : 0);
   w.gn_tile = (float*)take(H == 256 ? sizeof(float) * ((E + 255) / 256 * 8) * 64 : 0);   // per 32-edge tile: 32 x (sum, sumsq)
+  // operand scales of the fp16 split path: max |e| per 32-edge tile (fused kernel), one power of two per node row / edge row
+  w.etmax = (float*)take(H == 256 ? sizeof(float) * ((E + 255) / 256 * 8) : 0);
+  w.hscale = (float*)take(sizeof(float) * N);
+  w.escale = (float*)take(sizeof(float) * E);
   w.bytes = cur;
   return w;
 }
@@ -143,16 +148,17 @@ struct Profiler {
 struct ProfScope {
   hipStream_t st;
   bool active;
-  size_t slot;
-  ProfScope(int category, hipStream_t s) : st(s), active(false), slot(0) {
+  hipEvent_t end;      // handle copied while the lock is held: the destructor never touches the shared vectors
+  ProfScope(int category, hipStream_t s) : st(s), active(false), end(nullptr) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof.on || (g_prof.dominant_only && category != PROF_LINEAR_EDGE) || g_prof.used * 2 + 2 > g_prof.ev.size()) return;
-    slot = g_prof.used++;
+    const size_t slot = g_prof.used++;
     g_prof.cat[slot] = category;
+    end = g_prof.ev[2 * slot + 1];
     active = hipEventRecord(g_prof.ev[2 * slot], st) == hipSuccess;
   }
   ~ProfScope() {
-    if (active) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+    if (active) (void)hipEventRecord(end, st);
   }
 };
 
@@ -264,8 +270,16 @@ int difusco_denoise_step(const difusco_step_args* a) {
                          float* y) -> hipError_t {
     if (a->precision == DIFUSCO_PREC_FP32) return linear_rows(x, w, b, res, y, E, H, H, H, st);
     const unsigned short* pl = reinterpret_cast<const unsigned short*>(planes);
-    if (a->precision == DIFUSCO_PREC_FP16X3) pl += (long long)3 * H * H;   // fp16 planes follow the 3 bf16 planes
-    return linear_rows_split(x, pl, (long long)H * H, a->precision, b, res, y, E, H, H, H, st);
+    SplitScale sc;
+    if (a->precision == DIFUSCO_PREC_FP16X3) {
+      pl += (long long)3 * H * H;   // fp16 planes follow the 3 bf16 planes
+      // fp16 planes: per-row power-of-two scale of x (one extra pass over x on this unfused path), weight inverse scales
+      hipError_t er = launch_row_pow2_scale(x, E, H, ws.escale, st);
+      if (er != hipSuccess) return er;
+      sc.row_scale = ws.escale;
+      sc.w_inv = planes + (long long)5 * H * H / 2;
+    }
+    return linear_rows_split(x, pl, (long long)H * H, a->precision, b, res, y, E, H, H, H, st, 0, sc);
   };
 
   // PROF(category, call): HIP_TRY(call), bracketed by a pair of HIP events on `st` when profiling is on
@@ -285,10 +299,17 @@ int difusco_denoise_step(const difusco_step_args* a) {
   // kernel takes it from the table and the pass that would write e0 to HBM is skipped
   // last layer (at least two layers).  TSP: the fused kernel also emits the head's GroupNorm partial sums per tile and
   // skips the node update nobody reads; MIS: it skips the edge output nobody reads.
-  const bool tail_fold = fused && L >= 2 && difusco::g_fused_gn_fold != 0 && difusco::g_fused_ablate == 0;
+#ifdef DIFUSCO_PROFILING
+  const bool ablating = difusco::g_fused_ablate != 0;
+#else
+  const bool ablating = false;
+#endif
+  const bool tail_fold = fused && L >= 2 && (a->flags & DIFUSCO_FLAG_NO_TAIL_FOLD) == 0 && !ablating;
   const bool gn_fold = tail_fold && tsp;
-  const bool l0_fold = fused && difusco::g_fused_l0_fold != 0 &&
-                       difusco::g_fused_ablate == 0 && (tsp ? a->xt_is_binary != 0 : true);
+  const bool l0_fold = fused && (a->flags & DIFUSCO_FLAG_NO_L0_FOLD) == 0 && !ablating &&
+                       (tsp ? a->xt_is_binary != 0 : true);
+  const bool f16 = a->precision == DIFUSCO_PREC_FP16X3;
+  const int64_t n_tiles_pad = E_pad / 32;
 
   // per-layer time bias rows: time_layer_l(time_embed(timestep_embedding(t)))   [L,H]
   if (!head_only)
@@ -315,14 +336,19 @@ int difusco_denoise_step(const difusco_step_args* a) {
       if (l0_fold) {   // e0 and C e0 are read from ws.table by the first fused layer: C on the two rows, exact fp32
         PROF(PROF_EMBED, launch_two_rows_linear(H, ws.table, LW(0, DIFUSCO_WL_C_W), nullptr, ws.table + 2 * H, st))
       }
-      else if (fused) PROF(PROF_EMBED, launch_table_rows_tiled(a->xt, a->perm, ws.table, E, ws.e, st))
+      else if (fused) {
+        PROF(PROF_EMBED, launch_table_rows_tiled(a->xt, a->perm, ws.table, E, ws.e, st))
+        if (f16) PROF(PROF_EMBED, launch_tile_absmax_tiled(ws.e, n_tiles_pad, ws.etmax, st))
+      }
       else PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, ws.table, E, H, ws.e, st))
     } else {
       if (fused) {   // sinusoidal features generated inside the linear: the E x H embedding never exists in memory
         const unsigned short* pl = reinterpret_cast<const unsigned short*>(G(DIFUSCO_W_EDGE_EMBED_PLANES)) +
                                    (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0);
         PROF(PROF_EMBED, linear_scalar_embed_split(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), pl, (long long)H * H,
-                                                   a->precision, G(DIFUSCO_W_EDGE_EMBED_B), ws.e, E, st, /*tiled_out=*/1))
+                                                   a->precision, G(DIFUSCO_W_EDGE_EMBED_B), ws.e, E, st, /*tiled_out=*/1,
+                                                   G(DIFUSCO_W_EDGE_EMBED_PLANES) + (long long)5 * H * H / 2,
+                                                   f16 ? ws.etmax : nullptr))
       } else {
         PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
         PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_PLANES),
@@ -338,6 +364,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
       PROF(PROF_EMBED, zero_async(ws.e + (E / 32) * 32 * H, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
     } else if (E > 0) {
       PROF(PROF_EMBED, hipMemsetAsync(ws.e, 0, sizeof(float) * (fused ? E_pad : E) * H, st))
+      if (fused && f16) PROF(PROF_EMBED, hipMemsetAsync(ws.etmax, 0, sizeof(float) * n_tiles_pad, st))
     }
   }
 
@@ -347,8 +374,14 @@ int difusco_denoise_step(const difusco_step_args* a) {
     if (a->precision != DIFUSCO_PREC_FP32 && H == 256) {   // node rows on the same split-precision matrix-core path
       const unsigned short* npl = reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_NODE4_PLANES)) +
                                   (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * 4 * H * H : 0);
+      SplitScale sc;
+      if (f16) {   // row scales of h: left by node_finalize of the previous layer on the fused path, computed here otherwise
+        if (!fused || l == 0) PROF(PROF_LINEAR_NODE, launch_row_pow2_scale(ws.h, N, H, ws.hscale, st))
+        sc.row_scale = ws.hscale;
+        sc.w_inv = LW(l, DIFUSCO_WL_NODE4_PLANES) + (long long)5 * 4 * H * H / 2;
+      }
       PROF(PROF_LINEAR_NODE, linear_rows_split(ws.h, npl, (long long)4 * H * H, a->precision, LW(l, DIFUSCO_WL_NODE4_B),
-                                               nullptr, ws.node4, N, H, 4 * H, 4 * H, st))
+                                               nullptr, ws.node4, N, H, 4 * H, 4 * H, st, 0, sc))
     } else {
       PROF(PROF_LINEAR_NODE, linear_rows(ws.h, LW(l, DIFUSCO_WL_NODE4_W), LW(l, DIFUSCO_WL_NODE4_B), nullptr, ws.node4,
                                          N, H, 4 * H, 4 * H, st))
@@ -361,7 +394,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                       (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
                                       LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                       LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
-                                      ws.table, tsp ? a->xt : nullptr, tsp ? a->perm : nullptr, st))
+                                      ws.table, tsp ? a->xt : nullptr, tsp ? a->perm : nullptr,
+                                      LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st))
     } else if (fused && tail_fold && l == L - 1) {
       PROF(PROF_LINEAR_EDGE,
            launch_edge_layer_fused_tail(a->precision, tsp ? 1 : 2, ws.e, ws.node4, a->row, a->col, (int)E,
@@ -370,7 +404,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                       (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
                                       LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                       LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
-                                      ws.gn_tile, st))
+                                      ws.gn_tile, LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st))
     } else if (fused) {
       PROF(PROF_LINEAR_EDGE,
            launch_edge_layer_fused(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,
@@ -379,13 +413,13 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                    (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
                                    LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                    LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
-                                   st))
+                                   LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, ws.etmax, st))
     }
     if (fused && gn_fold && l == L - 1) continue;     // TSP: h is not read after the last layer
     if (fused) {
       PROF(PROF_GATE, launch_node_finalize((int)N, (int)E, a->rowptr, ws.node4, ws.part, ws.direct, ws.h,
                                            LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
-                                           ws.tbias + (size_t)l * H, tsp ? 1 : 0, st))
+                                           ws.tbias + (size_t)l * H, tsp ? 1 : 0, f16 ? ws.hscale : nullptr, st))
       continue;
     }
     PROF(PROF_LINEAR_EDGE, edge_linear(ws.e, LW(l, DIFUSCO_WL_C_W), LW(l, DIFUSCO_WL_C_PLANES), LW(l, DIFUSCO_WL_C_B),
@@ -427,16 +461,25 @@ int difusco_linear_rows(const float* x, const float* w, const float* bias, const
 }
 
 int difusco_linear_rows_split(const float* x, const void* planes, int precision, const float* bias,
-                              const float* residual, float* y, int64_t m, int k, int n_out, int64_t ldy, void* stream) {
+                              const float* residual, float* y, int64_t m, int k, int n_out, int64_t ldy,
+                              float* row_scale_scratch, void* stream) {
   if (!x || !planes || !y) return fail(DIFUSCO_EINVAL, "null pointer");
   if (precision < DIFUSCO_PREC_BF16X3 || precision > DIFUSCO_PREC_FP16X3)
     return fail(DIFUSCO_EINVAL, "precision must be BF16X3, BF16X6 or FP16X3");
   if (k != n_out || !(k == 64 || k == 128 || k == 256) || ldy < n_out)
     return fail(DIFUSCO_EINVAL, "split path needs k == n_out in {64,128,256}, ldy >= n_out");
   const unsigned short* pl = reinterpret_cast<const unsigned short*>(planes);
-  if (precision == DIFUSCO_PREC_FP16X3) pl += (long long)3 * n_out * k;
+  difusco::SplitScale sc;
+  if (precision == DIFUSCO_PREC_FP16X3) {
+    pl += (long long)3 * n_out * k;
+    sc.w_inv = reinterpret_cast<const float*>(planes) + (long long)5 * n_out * k / 2;
+    if (row_scale_scratch != nullptr) {
+      HIP_TRY(difusco::launch_row_pow2_scale(x, m, k, row_scale_scratch, (hipStream_t)stream));
+      sc.row_scale = row_scale_scratch;
+    }
+  }
   HIP_TRY(difusco::linear_rows_split(x, pl, (long long)n_out * k, precision, bias, residual, y, m, k, n_out, ldy,
-                                     (hipStream_t)stream));
+                                     (hipStream_t)stream, 0, sc));
   return DIFUSCO_OK;
 }
 
@@ -454,7 +497,7 @@ int difusco_edge_gate_aggregate(int hidden, int n_nodes, const int32_t* rowptr, 
 
 size_t difusco_fused_scratch_bytes(int n_nodes, int n_edges) {
   if (n_nodes < 0 || n_edges < 0) return 0;
-  return sizeof(float) * (fused_part_floats(n_edges) + (size_t)n_nodes * 256) + 256;
+  return sizeof(float) * (fused_part_floats(n_edges) + (size_t)n_nodes * 256 + (size_t)(n_edges + 255) / 256 * 8 + 64) + 256;
 }
 
 int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int32_t* rowptr, const int32_t* row,
@@ -462,23 +505,29 @@ int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int3
                              const void* planes_o, const float* b_c, const float* norm_h_w, const float* norm_h_b,
                              const float* norm_e_w, const float* norm_e_b, const float* out_ln_w,
                              const float* out_ln_b, const float* b_out, const float* tbias, int time_on_edge,
-                             void* scratch, void* stream) {
+                             const float* scales, void* scratch, void* stream) {
   if (precision != DIFUSCO_PREC_BF16X3 && precision != DIFUSCO_PREC_FP16X3)
     return fail(DIFUSCO_EINVAL, "fused kernel: precision must be BF16X3 or FP16X3");
   if (!rowptr || !row || !col || !node4 || !e || !h || !planes_c || !planes_o || !b_c || !norm_h_w || !norm_h_b ||
       !norm_e_w || !norm_e_b || !out_ln_w || !out_ln_b || !b_out || !tbias || !scratch)
     return fail(DIFUSCO_EINVAL, "null pointer");
+  if (precision == DIFUSCO_PREC_FP16X3 && !scales)
+    return fail(DIFUSCO_EINVAL, "fused kernel, FP16X3: the operand-scale record of the layer is required");
   const long long off = precision == DIFUSCO_PREC_FP16X3 ? 3LL * 256 * 256 : 0;
   float* part = reinterpret_cast<float*>(scratch);
   float* direct = part + (fused_part_floats(n_edges) + 63) / 64 * 64;
+  float* etmax = direct + (size_t)n_nodes * 256;
   hipStream_t st = (hipStream_t)stream;
+  const long long n_tiles_pad = ((long long)n_edges + 255) / 256 * 8;
+  if (precision == DIFUSCO_PREC_FP16X3)      // e-stream scale per tile: normally left by the producer of e
+    HIP_TRY(difusco::launch_tile_absmax_tiled(e, n_tiles_pad, etmax, st));
   HIP_TRY(difusco::launch_edge_layer_fused(precision, e, node4, row, col, n_edges,
                                            reinterpret_cast<const unsigned short*>(planes_c) + off,
                                            reinterpret_cast<const unsigned short*>(planes_o) + off, 256LL * 256, b_c,
                                            norm_e_w, norm_e_b, tbias, out_ln_w, out_ln_b, b_out, time_on_edge, part,
-                                           direct, st));
+                                           direct, scales, etmax, etmax, st));
   HIP_TRY(difusco::launch_node_finalize(n_nodes, n_edges, rowptr, node4, part, direct, h, norm_h_w, norm_h_b, tbias,
-                                        time_on_edge, st));
+                                        time_on_edge, nullptr, st));
   return DIFUSCO_OK;
 }
 
@@ -502,6 +551,7 @@ int difusco_gaussian_posterior(const float* pred, const float* xt, const float* 
   return DIFUSCO_OK;
 }
 
+#ifdef DIFUSCO_PROFILING
 int difusco_debug_set_ptr(int key, void* p) {
   if (key == 1) { difusco::g_fused_dbg = reinterpret_cast<unsigned long long*>(p); return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
@@ -509,13 +559,13 @@ int difusco_debug_set_ptr(int key, void* p) {
 
 int difusco_debug_set(int key, int value) {
   if (key == 0) { difusco::g_fused_ablate = value; return DIFUSCO_OK; }
-  if (key == 3) { difusco::g_fused_l0_fold = value; return DIFUSCO_OK; }
-  if (key == 4) { difusco::g_fused_gn_fold = value; return DIFUSCO_OK; }
   if (key == 6) { difusco::g_fused_lds_pad = value; return DIFUSCO_OK; }
+  if (key == 9) { difusco::g_fused_start_delay = value; return DIFUSCO_OK; }
   if (key == 7) { difusco::g_fused_opt = value; return DIFUSCO_OK; }
   if (key == 8 && (value == 1 || value == 4)) { difusco::g_node_linear_depth = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }
+#endif  // DIFUSCO_PROFILING
 
 int difusco_profile_enable(int on, int max_launches) {
   std::lock_guard<std::mutex> lk(g_prof_mu);

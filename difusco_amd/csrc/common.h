@@ -28,6 +28,22 @@ __device__ __forceinline__ void wave_sum2(float& a, float& b) {
   }
 }
 
+// Power-of-two scale that brings a non-negative maximum m into [2^14, 2^15): returns 2^k and writes 2^-k, k clamped to
+// [-100, 100] (m = 0, denormal or huge: the clamp; inf / nan inputs give garbage downstream either way).  Integer
+// arithmetic on the exponent field only.
+__device__ __forceinline__ float pow2_scale_for(float m, float& inv) {
+  int ex = (int)(__builtin_bit_cast(unsigned, m) >> 23) & 255;     // biased exponent of m
+  ex = ex < 41 ? 41 : (ex > 241 ? 241 : ex);
+  const int k = 141 - ex;                                          // m * 2^k in [2^14, 2^15)
+  inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+  return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+
+// sigmoid on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---- Philox4x32-10 (Salmon et al. 2011), counter-based: one call gives 4 x 32 random bits -------

@@ -15,7 +15,8 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
                                                             const float* __restrict__ direct, float* h,
                                                             const float* __restrict__ nh_w,
                                                             const float* __restrict__ nh_b,
-                                                            const float* __restrict__ tbias, int time_on_edge) {
+                                                            const float* __restrict__ tbias, int time_on_edge,
+                                                            float* __restrict__ row_scale) {
   constexpr int H = 256;
   const int lane = threadIdx.x & 63;
   const int f = lane * 4;
@@ -54,15 +55,25 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
     hv[q] += y;
   }
   *reinterpret_cast<v4f*>(hp) = hv;
+  if (row_scale != nullptr) {      // power-of-two operand scale of this row for the next node-row linear (fp16 planes)
+    float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(hv[0]), __builtin_fabsf(hv[1])),
+                              __builtin_fmaxf(__builtin_fabsf(hv[2]), __builtin_fabsf(hv[3])));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+    float inv;
+    const float sc = pow2_scale_for(m, inv);
+    if (lane == 0) row_scale[i] = sc;
+  }
 }
 
-int g_fused_ablate = 0;   // profiling knob (difusco_debug_set key 0), 0 in production
-int g_fused_lds_pad = 0;  // profiling only (difusco_debug_set key 6)
-int g_fused_gn_fold = 1;  // 1: last-layer variants - TSP: GroupNorm partial sums + no node update; MIS: no edge
-                          //    output (difusco_debug_set key 4)
-int g_fused_l0_fold = 1;  // 1: the first layer reads its edge input from the 2-row table (difusco_debug_set key 3)
-int g_fused_opt = FUSED_OPT;   // difusco_debug_set key 7: 0 = all scheduling options off (A/B), anything else = production
-unsigned long long* g_fused_dbg = nullptr;   // profiling: device buffer for phase timestamps, [n_tiles][8]
+#ifdef DIFUSCO_PROFILING
+// process-wide knobs of the PROFILING library (libdifusco_hip_prof.so, difusco_debug_set); the production library has none
+int g_fused_ablate = 0;   // ablation mask (difusco_debug_set key 0): wrong results by construction, timing only
+int g_fused_lds_pad = 0;  // extra dynamic LDS bytes: occupancy probe (key 6)
+int g_fused_start_delay = 0;   // cycles by which the second-slot workgroups of the first generation start late (key 9)
+int g_fused_opt = FUSED_OPT;   // key 7: A/B variants of the scheduling options
+unsigned long long* g_fused_dbg = nullptr;   // device buffer for phase timestamps, [n_tiles][16]
+#endif
 
 hipError_t launch_fused_fp16(int kind, FUSED_KIND_PARAMS) { return launch_fused_kind<FFp16>(kind, FUSED_KIND_ARGS); }
 
@@ -78,14 +89,17 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
                                    const unsigned short* c_planes, const unsigned short* o_planes,
                                    long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                    const float* tbias, const float* g_o, const float* b_o, const float* b_out,
-                                   int time_on_edge, float* part, float* direct, hipStream_t stream) {
+                                   int time_on_edge, float* part, float* direct, const float* scales,
+                                   const float* etmax_in, float* etmax_out, hipStream_t stream) {
   const float *l0_table = nullptr, *l0_x = nullptr;
   const int* l0_perm = nullptr;
   float* gn_tile = nullptr;
+#ifdef DIFUSCO_PROFILING
   if (mode == 3 && g_fused_ablate != 0) {      // profiling-only variants exist for the fp16 middle layer
     if (n_edges <= 0) return hipSuccess;
     return launch_fused_ablation(g_fused_ablate, FUSED_KIND_ARGS);
   }
+#endif
   return launch_by_mode(mode, 0, FUSED_KIND_ARGS);
 }
 
@@ -96,9 +110,11 @@ hipError_t launch_edge_layer_fused_tail(int mode, int tail, float* e, const floa
                                         int n_edges, const unsigned short* c_planes, const unsigned short* o_planes,
                                         long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                         const float* tbias, const float* g_o, const float* b_o, const float* b_out,
-                                        int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream) {
+                                        int time_on_edge, float* part, float* direct, float* gn_tile,
+                                        const float* scales, const float* etmax_in, hipStream_t stream) {
   const float *l0_table = nullptr, *l0_x = nullptr;
   const int* l0_perm = nullptr;
+  float* etmax_out = nullptr;
   if (tail != 1 && tail != 2) return hipErrorInvalidValue;
   return launch_by_mode(mode, tail == 1 ? 2 : 3, FUSED_KIND_ARGS);
 }
@@ -111,19 +127,20 @@ hipError_t launch_edge_layer_fused_l0(int mode, float* e, const float* node4, co
                                       long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                       const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                       int time_on_edge, float* part, float* direct, const float* table, const float* x,
-                                      const int* perm, hipStream_t stream) {
+                                      const int* perm, const float* scales, float* etmax_out, hipStream_t stream) {
   const float *l0_table = table, *l0_x = x;
   const int* l0_perm = perm;
   float* gn_tile = nullptr;
+  const float* etmax_in = nullptr;
   return launch_by_mode(mode, 1, FUSED_KIND_ARGS);
 }
 
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
-                                const float* tbias, int time_on_edge, hipStream_t stream) {
+                                const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream) {
   if (n_nodes <= 0) return hipSuccess;
   hipLaunchKernelGGL(node_finalize_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, stream, n_nodes, n_edges,
-                     rowptr, node4, part, direct, h, nh_w, nh_b, tbias, time_on_edge);
+                     rowptr, node4, part, direct, h, nh_w, nh_b, tbias, time_on_edge, row_scale);
   return hipGetLastError();
 }
 

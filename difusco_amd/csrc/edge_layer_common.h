@@ -13,7 +13,11 @@ typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
+// kScaled: the 16-bit format has a narrow exponent range (fp16: normal numbers 2^-14 .. 65504), so operands are brought
+// into its upper binades by exact power-of-two scales before they are split (weights: on the host, weights.py;
+// activations: in registers) and the scale is undone where the bias is added.  bf16 has the fp32 exponent range.
 struct FBf16 {
+  static constexpr bool kScaled = false;
   typedef v8bf frag;
   __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
     v2f f = {a, b};
@@ -28,6 +32,7 @@ struct FBf16 {
   }
 };
 struct FFp16 {
+  static constexpr bool kScaled = true;
   typedef v8h frag;
   __device__ static __forceinline__ unsigned split_pair(float& a, float& b) {
     v2f f = {a, b};
@@ -69,10 +74,16 @@ __device__ __forceinline__ v2f fast_sigmoid2(v2f x) {
   return v2f{__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
 }
 #define DIFUSCO_PAIR(v, i) (v2f{(v)[(i)], (v)[(i) + 1]})
-
-// sigmoid on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each)
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+// sigmoid(x) for an argument that arrives pre-scaled, xs = x * 2^k: nsig = -log2(e) * 2^-k (a power-of-two multiple of the
+// constant above, so xs * nsig has the bits of x * -log2(e))
+__device__ __forceinline__ v2f fast_sigmoid2s(v2f xs, float nsig) {
+  v2f t = xs * v2f{nsig, nsig};
+  t = v2f{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  t = v2f{1.0f, 1.0f} + t;
+  return v2f{__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+}
+__device__ __forceinline__ float fast_sigmoid_s(float xs, float nsig) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(nsig * xs));
 }
 
 }  // namespace difusco

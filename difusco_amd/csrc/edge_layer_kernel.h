@@ -87,7 +87,15 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     const float* __restrict__ b_out, int time_on_edge, float* __restrict__ part, float* __restrict__ direct,
     unsigned long long* dbg,     // dbg: optional phase timestamps (profiling), nullptr in production
     const float* __restrict__ l0_table, const float* __restrict__ l0_x, const int* __restrict__ l0_perm,
-    float* __restrict__ gn_tile) {
+    float* __restrict__ gn_tile, const float* __restrict__ scales, const float* __restrict__ etmax_in,
+    float* __restrict__ etmax_out, int start_delay) {
+  // Operand scaling (T::kScaled, i.e. fp16 planes; see edge_layer_common.h).  scales = {2^-kc, 2^-(ko+ka), 2^ka, -log2(e) 2^-ka}:
+  // the weight planes of C / W_o hold W 2^kc / W 2^ko (weights.py), the activation of GEMM 2 is produced as a 2^ka with ka
+  // from the host-side bound |a| <= 16 max|g_o| + max|b_o| (LayerNorm output is bounded by sqrt(H - 1)), and the e stream
+  // of GEMM 1 is scaled per 32-edge tile by 2^kx, kx from the tile's max|e| that the PRODUCER of e left in etmax_in[tile]
+  // (the previous layer's output phase writes etmax_out, the embedding kernels do the same).  Every scale is a power of
+  // two, so products and sums are the exact scaled values and one multiply in the epilogue (fused into the bias add)
+  // restores them: the two-plane split then keeps its 22 significand bits for any finite fp32 operand scale.
   // TAIL: what the step still needs from this layer.  0 = everything.  1 = last layer of a TSP step: the head reads
   // only e, so the node update is dead work - no V h gathers, no gate, no neighbour sum (the caller skips
   // node_finalize).  2 = last layer of a MIS step: the head reads only h, so the edge output is dead work - the kernel
@@ -140,6 +148,17 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
   }
+  // start_delay > 0 (experiment, profiling library): the workgroups that take the SECOND slot of every CU in the first
+  // dispatch generation (positions 32..63 of their XCD) start that many cycles late, so that the two resident workgroups of
+  // a CU begin out of phase (one in its matrix phases while the other is in its VALU phases); later generations inherit
+  // the offset because a workgroup starts when its predecessor in the slot ends.
+  if (start_delay > 0) {
+    const int pos = (int)blockIdx.x >> 3;
+    if (pos >= 32 && pos < 64) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)start_delay) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   const int tile = bid * WAVES + wave;
   const int s_raw = tile * 32 + l31;
   const bool valid = s_raw < n_edges;
@@ -184,6 +203,18 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     else *reinterpret_cast<v4f*>(p) = v;
   };
   float* scr = scr_all + wave * 32 * SCR_STRIDE;
+  float sx = 1.0f, inv1 = 1.0f, inv2 = 1.0f, sa = 1.0f, nsig = -1.4426950408889634f;
+  if constexpr (T::kScaled) {
+    inv2 = scales[1];
+    sa = scales[2];
+    nsig = scales[3];
+    if constexpr (!L0) {
+      float invx;
+      sx = pow2_scale_for(etmax_in[tile], invx);      // (tile is wave uniform: scalar load, scalar arithmetic)
+      inv1 = scales[0] * invx;
+    }
+  }
+  float tmx = 0.0f;      // max |e_new| over this lane's share of the tile (kScaled: becomes etmax_out[tile])
   // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
   unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define FUSED_STAMP(k) \
@@ -275,8 +306,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     prm[P_GE * H + tid] = g_e[tid];
     prm[P_BE * H + tid] = b_e[tid];
     prm[P_T * H + tid] = time_on_edge ? tbias[tid] : 0.0f;
-    prm[P_GO * H + tid] = g_o[tid];
-    prm[P_BO * H + tid] = b_o[tid];
+    prm[P_GO * H + tid] = g_o[tid] * sa;      // LN_o output arrives as z 2^ka (exact)
+    prm[P_BO * H + tid] = b_o[tid] * sa;
     prm[P_BOUT * H + tid] = b_out[tid];
     if constexpr (L0) {
       prm[P_TAB0 * H + tid] = l0_table[tid];
@@ -342,6 +373,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           er[ks % RING][0] = ld_e((ks + RING) * 512, kBufRing);
           er[ks % RING][1] = ld_e(((ks + RING) * 512 + 256), kBufRing);
         }
+      }
+      if constexpr (T::kScaled) {
+        c0 = c0 * sx;
+        c1 = c1 * sx;
       }
       const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       split8<T>(xs, xh[sub], xl[sub]);
@@ -476,7 +511,9 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const int r = 4 * g + 2 * h2;
-          const v2f ce = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(bc, 2 * h2);
+          v2f ce;
+          if constexpr (T::kScaled && !L0) ce = DIFUSCO_PAIR(acc1[nb], r) * v2f{inv1, inv1} + DIFUSCO_PAIR(bc, 2 * h2);
+          else ce = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(bc, 2 * h2);
           const v2f ev = (DIFUSCO_PAIR(ah, 2 * h2) + DIFUSCO_PAIR(bh, 2 * h2)) + ce;
           acc1[nb][r] = ev[0];
           acc1[nb][r + 1] = ev[1];
@@ -490,7 +527,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float ce = acc1[nb][4 * g + q] + bc[q];
+        const float ce = (T::kScaled && !L0) ? acc1[nb][4 * g + q] * inv1 + bc[q] : acc1[nb][4 * g + q] + bc[q];
         const float ev = (ah[q] + bh[q]) + ce;
         acc1[nb][4 * g + q] = ev;
         if constexpr (kPart) s1p[q] += ev; else s1 += ev;
@@ -649,7 +686,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
             const v2f z = DIFUSCO_PAIR(acc1[nb], 4 * g + 2 * h2) * v2f{rstd2, rstd2} * DIFUSCO_PAIR(go, 2 * h2) + DIFUSCO_PAIR(bo, 2 * h2);
-            const v2f a = z * fast_sigmoid2(z);
+            const v2f a = z * fast_sigmoid2s(z, nsig);
             a8[4 * g2 + 2 * h2] = a[0];
             a8[4 * g2 + 2 * h2 + 1] = a[1];
           }
@@ -657,7 +694,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float z = acc1[nb][4 * g + q] * rstd2 * go[q] + bo[q];
-          a8[4 * g2 + q] = skip_math ? z : z * fast_sigmoid(z);
+          a8[4 * g2 + q] = skip_math ? z : z * fast_sigmoid_s(z, nsig);
         }
         }
       }
@@ -760,15 +797,24 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           if constexpr (kPk) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-              const v2f o = DIFUSCO_PAIR(ein[nbp][g], 2 * h2) + (DIFUSCO_PAIR(acc2[nbp], 4 * g + 2 * h2) + DIFUSCO_PAIR(bo, 2 * h2));
+              v2f o;
+              if constexpr (T::kScaled)
+                o = DIFUSCO_PAIR(ein[nbp][g], 2 * h2) + (DIFUSCO_PAIR(acc2[nbp], 4 * g + 2 * h2) * v2f{inv2, inv2} + DIFUSCO_PAIR(bo, 2 * h2));
+              else
+                o = DIFUSCO_PAIR(ein[nbp][g], 2 * h2) + (DIFUSCO_PAIR(acc2[nbp], 4 * g + 2 * h2) + DIFUSCO_PAIR(bo, 2 * h2));
               v[2 * h2] = o[0];
               v[2 * h2 + 1] = o[1];
             }
           } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = ein[nbp][g][q] + (acc2[nbp][4 * g + q] + bo[q]);
+            for (int q = 0; q < 4; ++q)
+              v[q] = ein[nbp][g][q] + (T::kScaled ? acc2[nbp][4 * g + q] * inv2 + bo[q] : acc2[nbp][4 * g + q] + bo[q]);
           }
           st_e(((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256), v);
+          if constexpr (T::kScaled && !GNP) {      // (v_max3_f32 with |.| source modifiers)
+            tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+            tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+          }
           if constexpr (GNP) {
             gs[nbp * 4 + g] = (v[0] + v[1]) + (v[2] + v[3]);
             gq[nbp * 4 + g] = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -800,6 +846,13 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     }
     if (qt == 0) { FUSED_STAMP(8) }
   }
+  if constexpr (T::kScaled && !GNP) {      // the next layer's GEMM 1 scales this tile by its max |e| (pad lanes: 0)
+    if (etmax_out != nullptr) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) tmx = __builtin_fmaxf(tmx, __shfl_xor(tmx, off, 64));
+      if (lane == 0) etmax_out[tile] = tmx;
+    }
+  }
   FUSED_STAMP(9)
   if constexpr ((ABL & 16) != 0) {
     if (dbg != nullptr && lane == 0) {
@@ -814,6 +867,15 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #undef FUSED_DMA_PIECE
 }
 
+#ifdef DIFUSCO_PROFILING
+#define FUSED_LDS_PAD g_fused_lds_pad
+#define FUSED_DBG g_fused_dbg
+#define FUSED_START_DELAY g_fused_start_delay
+#else
+#define FUSED_LDS_PAD 0
+#define FUSED_DBG nullptr
+#define FUSED_START_DELAY 0
+#endif
 #define FUSED_OPT 3955       // production scheduling options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10, 11 of the kernel)
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
@@ -822,8 +884,9 @@ hipError_t launch_fused_t(float* e, const float* node4, const int* row, const in
                                  const unsigned short* c_planes, const unsigned short* o_planes, long long plane_stride,
                                  const float* b_c, const float* g_e, const float* b_e, const float* tbias,
                                  const float* g_o, const float* b_o, const float* b_out, int time_on_edge, float* part,
-                                 float* direct, hipStream_t stream, const float* l0_table = nullptr,
-                                 const float* l0_x = nullptr, const int* l0_perm = nullptr, float* gn_tile = nullptr) {
+                                 float* direct, hipStream_t stream, const float* l0_table, const float* l0_x,
+                                 const int* l0_perm, float* gn_tile, const float* scales, const float* etmax_in,
+                                 float* etmax_out) {
   static std::atomic<unsigned long long> attr_devices{0};      // per kernel instantiation: devices already configured
   {
     hipError_t er = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL, OPT>),
@@ -832,17 +895,21 @@ hipError_t launch_fused_t(float* e, const float* node4, const int* row, const in
   }
   constexpr int WV = fused::geo_waves(NW);
   const unsigned grid = (unsigned)((n_edges + 32 * WV - 1) / (32 * WV));
-  // profiling: g_fused_lds_pad extra bytes of dynamic LDS lower the number of co-resident workgroups per CU
+  // profiling builds: FUSED_LDS_PAD extra bytes of dynamic LDS lower the number of co-resident workgroups per CU
   hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL, OPT>), dim3(grid), dim3(64 * WV),
-                     fused::Geo<NW>::LDS_TOTAL + g_fused_lds_pad, stream,
+                     fused::Geo<NW>::LDS_TOTAL + FUSED_LDS_PAD, stream,
                      e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
-                     time_on_edge, part, direct, g_fused_dbg, l0_table, l0_x, l0_perm, gn_tile);
+                     time_on_edge, part, direct, FUSED_DBG, l0_table, l0_x, l0_perm, gn_tile, scales, etmax_in, etmax_out, FUSED_START_DELAY);
   return hipGetLastError();
 }
 
-// production geometry, no ablation; the scheduling options come from g_fused_opt (bit-identical results)
+// production geometry, no ablation.  Profiling builds (-DDIFUSCO_PROFILING, libdifusco_hip_prof.so) also hold the A/B
+// variants of the scheduling options, selected by g_fused_opt; the production library has the production set only.
 template <typename T, bool L0, bool GNP, int TAIL, typename... A>
 hipError_t launch_fused_opt(A... args) {
+#ifndef DIFUSCO_PROFILING
+  return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
+#else
   switch (g_fused_opt) {
     case 0: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 0>(args...);
     case 115: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 115>(args...);      // (A/B: e stream by 64-bit lane addresses)
@@ -851,6 +918,7 @@ hipError_t launch_fused_opt(A... args) {
     case 1907: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 1907>(args...);    // (A/B: scalar element-wise arithmetic)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
+#endif
 }
 
 // one entry point per element type / purpose, each defined in its own translation unit.
@@ -860,10 +928,11 @@ hipError_t launch_fused_opt(A... args) {
   float *e, const float *node4, const int *row, const int *col, int n_edges, const unsigned short *c_planes,          \
       const unsigned short *o_planes, long long plane_stride, const float *b_c, const float *g_e, const float *b_e,   \
       const float *tbias, const float *g_o, const float *b_o, const float *b_out, int time_on_edge, float *part,      \
-      float *direct, hipStream_t stream, const float *l0_table, const float *l0_x, const int *l0_perm, float *gn_tile
+      float *direct, hipStream_t stream, const float *l0_table, const float *l0_x, const int *l0_perm, float *gn_tile,  \
+      const float *scales, const float *etmax_in, float *etmax_out
 #define FUSED_KIND_ARGS                                                                                                \
   e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out, time_on_edge, \
-      part, direct, stream, l0_table, l0_x, l0_perm, gn_tile
+      part, direct, stream, l0_table, l0_x, l0_perm, gn_tile, scales, etmax_in, etmax_out
 hipError_t launch_fused_fp16(int kind, FUSED_KIND_PARAMS);
 hipError_t launch_fused_bf16(int kind, FUSED_KIND_PARAMS);
 hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS);      // profiling-only variants of the fp16 middle layer

@@ -461,6 +461,25 @@ __global__ __launch_bounds__(256) void table_rows_tiled_kernel(const float* __re
   *reinterpret_cast<v4f*>(out + p4 * 4) = *reinterpret_cast<const v4f*>(table + (xv > 0.5f ? 256 : 0) + f);
 }
 
+// max |e| per 32-edge tile of the tiled buffer (the e-stream scale of the fused kernel's fp16 planes) for producers of e
+// that do not emit it themselves.  One wavefront per tile: 32 float4 per lane.
+__global__ __launch_bounds__(256) void tile_absmax_tiled_kernel(const float* __restrict__ feat, long long n_tiles,
+                                                                float* __restrict__ tile_max) {
+  const int lane = threadIdx.x & 63;
+  const long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (t >= n_tiles) return;
+  float m = 0.0f;
+#pragma unroll 8
+  for (int c = 0; c < 32; ++c) {
+    const v4f x = *reinterpret_cast<const v4f*>(feat + t * 8192 + c * 256 + lane * 4);
+    m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(x[0])), __builtin_fabsf(x[1]));
+    m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(x[2])), __builtin_fabsf(x[3]));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) tile_max[t] = m;
+}
+
 // GroupNorm partial sums on the tiled buffer: a KiB chunk (tile, c = 2 ks + i) holds 8 channels = ONE group c of
 // 32 edges.  Block b: groups 4 (b % 8) + wave, tiles b / 8, b / 8 + gridDim.x / 8, ...  Pad lanes hold zeros.
 __global__ __launch_bounds__(256) void gn_partial_tiled_kernel(const float* __restrict__ feat, long long n_tiles,
@@ -688,6 +707,12 @@ hipError_t launch_gaussian_posterior(const float* pred, const float* xt, const f
   pp.rand_mode = rand_mode; pp.rand = rand; pp.seed = seed; pp.offset = offset;
   hipLaunchKernelGGL(gaussian_posterior_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pred, xt, pp,
                      xt_out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_tile_absmax_tiled(const float* e, long long n_tiles, float* tile_max, hipStream_t stream) {
+  if (n_tiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(tile_absmax_tiled_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, stream, e, n_tiles, tile_max);
   return hipGetLastError();
 }
 

@@ -35,42 +35,61 @@ __host__ __device__ inline long long edge_tiled_offset(long long s, int f) {
 hipError_t linear_rows(const float* x, const float* w, const float* bias, const float* residual, float* y,
                        long long m, int k, int n_out, long long ldy, hipStream_t stream);
 
+// Operand scaling of the fp16 split path (all exact powers of two; defaults = no scaling, which is what the bf16
+// modes use): X row r is multiplied by x_scale * row_scale[r] before the split, the planes hold W[f] / w_inv[f], and the
+// accumulator is multiplied by the inverses where the bias is added.  tile_max (tiled output, n_out == 256): max |Y| per
+// 32-row tile - the per-tile e-stream scale the fused edge kernel reads.
+struct SplitScale {
+  const float* row_scale = nullptr;
+  float x_scale = 1.0f;
+  const float* w_inv = nullptr;
+  float* tile_max = nullptr;
+};
+
 // tiled_out != 0 (k == n_out == 256 only): Y is written in the tiled layout above instead of row major
 hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int mode,
                              const float* bias, const float* residual, float* y, long long m, int k, int n_out,
-                             long long ldy, hipStream_t stream, int tiled_out = 0);
+                             long long ldy, hipStream_t stream, int tiled_out = 0, SplitScale sc = SplitScale());
 
 // Y = ScalarEmbeddingSine(x[perm]) W^T + b, the [m,256] embedding generated inside the kernel (split planes, modes 1 / 3)
 hipError_t linear_scalar_embed_split(const float* x, const int* perm, const float* dimt, const unsigned short* wp,
                                      long long plane_stride, int mode, const float* bias, float* y, long long m,
-                                     hipStream_t stream, int tiled_out);
+                                     hipStream_t stream, int tiled_out, const float* w_inv, float* tile_max);
+
+// scale[r] = power-of-two operand scale of row r of x[m][k] (fp16 split path)
+hipError_t launch_row_pow2_scale(const float* x, long long m, int k, float* scale, hipStream_t stream);
+// tile_max[t] = max |e| over the 32-edge tile t of a TILED [rows_padded, 256] buffer
+hipError_t launch_tile_absmax_tiled(const float* e, long long n_tiles, float* tile_max, hipStream_t stream);
 
 hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
                                    const unsigned short* c_planes, const unsigned short* o_planes,
                                    long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                    const float* tbias, const float* g_o, const float* b_o, const float* b_out,
-                                   int time_on_edge, float* part, float* direct, hipStream_t stream);
-extern int g_fused_ablate;
+                                   int time_on_edge, float* part, float* direct, const float* scales,
+                                   const float* etmax_in, float* etmax_out, hipStream_t stream);
 hipError_t launch_edge_layer_fused_l0(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
                                       const unsigned short* c_planes, const unsigned short* o_planes,
                                       long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                       const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                       int time_on_edge, float* part, float* direct, const float* table, const float* x,
-                                      const int* perm, hipStream_t stream);
-extern int g_fused_l0_fold;
+                                      const int* perm, const float* scales, float* etmax_out, hipStream_t stream);
 hipError_t launch_edge_layer_fused_tail(int mode, int tail, float* e, const float* node4, const int* row, const int* col,
                                         int n_edges, const unsigned short* c_planes, const unsigned short* o_planes,
                                         long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                         const float* tbias, const float* g_o, const float* b_o, const float* b_out,
-                                        int time_on_edge, float* part, float* direct, float* gn_tile, hipStream_t stream);
-extern int g_fused_gn_fold;
+                                        int time_on_edge, float* part, float* direct, float* gn_tile,
+                                        const float* scales, const float* etmax_in, hipStream_t stream);
+#ifdef DIFUSCO_PROFILING
+extern int g_fused_ablate;
 extern int g_fused_lds_pad;
+extern int g_fused_start_delay;
 extern int g_fused_opt;
 extern int g_node_linear_depth;
 extern unsigned long long* g_fused_dbg;
+#endif
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
-                                const float* tbias, int time_on_edge, hipStream_t stream);
+                                const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream);
 
 hipError_t launch_time_bias(float t, int H, int n_layers, const float* freqs, const float* w0, const float* b0,
                             const float* w2, const float* b2, const float* wl_base, long long layer_stride,

@@ -77,8 +77,15 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
                                                                     const float* __restrict__ bias,
                                                                     const float* residual, float* Y, long long M,
                                                                     long long ldy, int tiled_out,
-                                                                    const int* __restrict__ gen_perm = nullptr,
-                                                                    const float* __restrict__ gen_dimt = nullptr) {
+                                                                    const int* __restrict__ gen_perm,
+                                                                    const float* __restrict__ gen_dimt,
+                                                                    const float* __restrict__ row_scale, float x_scale,
+                                                                    const float* __restrict__ w_inv,
+                                                                    float* __restrict__ tile_max) {
+  // Operand scaling for the fp16 planes (exact powers of two, see edge_layer_common.h): row r of X is multiplied by
+  // x_scale * row_scale[r] before it is split (row_scale: what the producer of X left per row, or null), the weight
+  // planes hold W[f] / w_inv[f] (weights.py), and the accumulator is multiplied by the product of the inverses where the
+  // bias is added.  tile_max (tiled output only): max |Y| per 32-row tile, the e-stream scale of the fused edge kernel.
   constexpr int RB = 128, NB = FB / 32, BK = 16;
   constexpr int RS = 24;                 // LDS row stride in bf16 elements (32 B data + 16 B pad = 48 B)
   constexpr int WV = (FB * 2 + 255) / 256;  // 16-byte chunks per thread per weight plane per slab
@@ -110,6 +117,13 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
 
   v4f xr_[D][2];
   v4u wr_[D][NS][WV];
+  float xsc[2];      // operand scale of the two X rows this thread stages
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    long long gr = r0 + ((tid + 256 * i) >> 2);
+    gr = gr < M ? gr : M - 1;
+    xsc[i] = x_scale * (row_scale != nullptr ? row_scale[gr] : 1.0f);
+  }
 
 #define DIFUSCO_LOAD(KT, SLOT)                                                                            \
   {                                                                                                   \
@@ -143,7 +157,8 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
       const int idx = tid + 256 * i;                                                                  \
       const int row = idx >> 2, c4 = idx & 3;                                                         \
-      float a = xr_[SLOT][i][0], b = xr_[SLOT][i][1], c = xr_[SLOT][i][2], d = xr_[SLOT][i][3];                                   \
+      float a = xr_[SLOT][i][0] * xsc[i], b = xr_[SLOT][i][1] * xsc[i], c = xr_[SLOT][i][2] * xsc[i],  \
+            d = xr_[SLOT][i][3] * xsc[i];                                                               \
       _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                                \
         v2u pk;                                                                                       \
         pk[0] = T::split_pair(a, b);                                                                  \
@@ -203,26 +218,42 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
 #undef DIFUSCO_STORE
 
   const long long row = r0 + wave * 32 + l31;
+  float tmx = 0.0f;
   if (row < M) {
+    float rinv = 1.0f;      // 1 / (x_scale * row_scale[row]): exact, both are powers of two
+    {
+      const float sc = x_scale * (row_scale != nullptr ? row_scale[row] : 1.0f);
+      rinv = __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, sc));
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int f = f0 + nb * 32 + 8 * g + 4 * hh;
         v4f v = {acc[nb][4 * g + 0], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
+        if (w_inv != nullptr) v = v * (*reinterpret_cast<const v4f*>(w_inv + f) * rinv);
+        else v = v * rinv;
         if (bias != nullptr) v += *reinterpret_cast<const v4f*>(bias + f);
         if (residual != nullptr) v += *reinterpret_cast<const v4f*>(residual + row * ldy + f);
         if (tiled_out) *reinterpret_cast<v4f*>(Y + edge_tiled_offset(row, f)) = v;   // f % 4 == 0: one aligned float4
         else *reinterpret_cast<v4f*>(Y + row * ldy + f) = v;
+        tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+        tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
       }
     }
+  }
+  if (tile_max != nullptr) {      // (FB == n_out: this wave holds every feature of its 32 rows)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tmx = __builtin_fmaxf(tmx, __shfl_xor(tmx, off, 64));
+    if (lane == 0) tile_max[(r0 >> 5) + wave] = tmx;
   }
 }
 
 template <int K, int FB, int NS, typename T, bool GEN = false, int D = 1>
 static hipError_t launch_split(const float* x, const unsigned short* wp, long long plane_stride, const float* bias,
                                const float* residual, float* y, long long m, int n_out, long long ldy, hipStream_t stream,
-                               int tiled_out, const int* gen_perm = nullptr, const float* gen_dimt = nullptr) {
+                               int tiled_out, const int* gen_perm, const float* gen_dimt, const float* row_scale,
+                               float x_scale, const float* w_inv, float* tile_max) {
   constexpr size_t lds = (size_t)NS * (128 + FB) * 24 * sizeof(unsigned short);
   static std::atomic<unsigned long long> attr_devices{0};
   {
@@ -232,34 +263,41 @@ static hipError_t launch_split(const float* x, const unsigned short* wp, long lo
   dim3 grid((unsigned)((m + 127) / 128), (unsigned)(n_out / FB));
   if (D > 1) grid = dim3((unsigned)(8 * (((m + 127) / 128 + 7) / 8) * (n_out / FB)), 1);
   hipLaunchKernelGGL((linear_rows_split_kernel<K, FB, NS, T, GEN, D>), grid, dim3(256), lds, stream, x, wp, plane_stride, n_out,
-                     bias, residual, y, m, ldy, tiled_out, gen_perm, gen_dimt);
+                     bias, residual, y, m, ldy, tiled_out, gen_perm, gen_dimt, row_scale, x_scale, w_inv, tile_max);
   return hipGetLastError();
 }
 
-int g_node_linear_depth = 4;     // k steps of global-load lookahead in the node-row linear (difusco_debug_set key 8: 1 or 4)
+#ifdef DIFUSCO_PROFILING
+int g_node_linear_depth = 4;     // A/B knob of the profiling library (difusco_debug_set key 8: 1 or 4 k steps of lookahead)
+#define NODE_LINEAR_DEPTH g_node_linear_depth
+#else
+#define NODE_LINEAR_DEPTH 4
+#endif
 
 // wp: first plane of the chosen element type, plane p at wp + p*plane_stride, each [K/16][n_out][16]
 // (k-permuted).  mode: 1 = bf16 x 2 planes (3 products), 2 = bf16 x 3 planes (6 products),
-// 3 = fp16 x 2 planes (3 products).
+// 3 = fp16 x 2 planes (3 products).  sc: operand scaling of the fp16 path (kernels.h: SplitScale).
 hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long plane_stride, int mode,
                              const float* bias, const float* residual, float* y, long long m, int k, int n_out,
-                             long long ldy, hipStream_t stream, int tiled_out) {
+                             long long ldy, hipStream_t stream, int tiled_out, SplitScale sc) {
   if (m <= 0) return hipSuccess;
   if (mode < 1 || mode > 3) return hipErrorInvalidValue;
   if (tiled_out && (k != 256 || n_out != 256 || residual != nullptr)) return hipErrorInvalidValue;
-#define DIFUSCO_SPLIT_CASE(KK, FBB)                                                                                   \
-  if (k == KK && n_out % FBB == 0) {                                                                                  \
-    if (mode == 1) return launch_split<KK, FBB, 2, Bf16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out); \
-    if (mode == 2) return launch_split<KK, FBB, 3, Bf16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out); \
-    return launch_split<KK, FBB, 2, Fp16>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out);    \
+  if (sc.tile_max != nullptr && !tiled_out) return hipErrorInvalidValue;
+#define DIFUSCO_SPLIT_ARGS x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out, nullptr, nullptr, sc.row_scale, sc.x_scale, sc.w_inv, sc.tile_max
+#define DIFUSCO_SPLIT_CASE(KK, FBB)                                                   \
+  if (k == KK && n_out % FBB == 0) {                                                  \
+    if (mode == 1) return launch_split<KK, FBB, 2, Bf16>(DIFUSCO_SPLIT_ARGS);         \
+    if (mode == 2) return launch_split<KK, FBB, 3, Bf16>(DIFUSCO_SPLIT_ARGS);         \
+    return launch_split<KK, FBB, 2, Fp16>(DIFUSCO_SPLIT_ARGS);                        \
   }
   // few row tiles (node rows): 128-column blocks give twice the workgroups, i.e. two per CU instead of one
   // (node linears 0.49 -> 0.42 ms/step at 8000 rows x 1024 outputs; 64-column blocks measured slower: 0.475;
   // round 2: two / four k slabs per LDS step - half / a quarter of the barriers - measured 0.433 / 0.546 vs 0.431 ms/step)
   if (k == 256 && !tiled_out && n_out % 128 == 0 && ((m + 127) / 128) * (n_out / 256) < 512) {
-    if (g_node_linear_depth == 4) {      // (difusco_debug_set key 8 = 1 restores the one-step lookahead for A/B)
-      if (mode == 1) return launch_split<256, 128, 2, Bf16, false, 4>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out);
-      if (mode == 3) return launch_split<256, 128, 2, Fp16, false, 4>(x, wp, plane_stride, bias, residual, y, m, n_out, ldy, stream, tiled_out);
+    if (NODE_LINEAR_DEPTH == 4) {      // (profiling library: key 8 = 1 restores the one-step lookahead for A/B)
+      if (mode == 1) return launch_split<256, 128, 2, Bf16, false, 4>(DIFUSCO_SPLIT_ARGS);
+      if (mode == 3) return launch_split<256, 128, 2, Fp16, false, 4>(DIFUSCO_SPLIT_ARGS);
     }
     DIFUSCO_SPLIT_CASE(256, 128)
   }
@@ -267,19 +305,46 @@ hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long
   DIFUSCO_SPLIT_CASE(128, 128)
   DIFUSCO_SPLIT_CASE(64, 64)
 #undef DIFUSCO_SPLIT_CASE
+#undef DIFUSCO_SPLIT_ARGS
   return hipErrorInvalidValue;
 }
 
 // Y = ScalarEmbeddingSine(x) W^T + b with the embedding generated inside the kernel (k = n_out = 256 only; modes 1 and 3).
+// The generated operand is sin / cos, |.| <= 1: its fp16 planes are scaled by the constant 2^14.
 hipError_t linear_scalar_embed_split(const float* x, const int* perm, const float* dimt, const unsigned short* wp,
                                      long long plane_stride, int mode, const float* bias, float* y, long long m,
-                                     hipStream_t stream, int tiled_out) {
+                                     hipStream_t stream, int tiled_out, const float* w_inv, float* tile_max) {
   if (m <= 0) return hipSuccess;
+  if (tile_max != nullptr && !tiled_out) return hipErrorInvalidValue;
   if (mode == 1)
-    return launch_split<256, 256, 2, Bf16, true>(x, wp, plane_stride, bias, nullptr, y, m, 256, 256, stream, tiled_out, perm, dimt);
+    return launch_split<256, 256, 2, Bf16, true>(x, wp, plane_stride, bias, nullptr, y, m, 256, 256, stream, tiled_out, perm, dimt,
+                                                 nullptr, 1.0f, nullptr, tile_max);
   if (mode == 3)
-    return launch_split<256, 256, 2, Fp16, true>(x, wp, plane_stride, bias, nullptr, y, m, 256, 256, stream, tiled_out, perm, dimt);
+    return launch_split<256, 256, 2, Fp16, true>(x, wp, plane_stride, bias, nullptr, y, m, 256, 256, stream, tiled_out, perm, dimt,
+                                                 nullptr, 16384.0f, w_inv, tile_max);
   return hipErrorInvalidValue;
+}
+
+// scale[r] = 2^k with max_c |x[r][c]| 2^k in [2^14, 2^15) (k clamped, see pow2_scale_for): the per-row operand scale of the
+// fp16 split path.  One wavefront per row.
+__global__ __launch_bounds__(256) void row_pow2_scale_kernel(const float* __restrict__ x, long long m, int k,
+                                                             float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const long long r = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= m) return;
+  float mx = 0.0f;
+  for (int c = lane; c < k; c += 64) mx = __builtin_fmaxf(mx, __builtin_fabsf(x[r * k + c]));
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, off, 64));
+  float inv;
+  const float sc = pow2_scale_for(mx, inv);
+  if (lane == 0) scale[r] = sc;
+}
+
+hipError_t launch_row_pow2_scale(const float* x, long long m, int k, float* scale, hipStream_t stream) {
+  if (m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(row_pow2_scale_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, x, m, k, scale);
+  return hipGetLastError();
 }
 
 }  // namespace difusco

@@ -68,14 +68,14 @@ int64_t workspace_bytes(int64_t hidden, int64_t n_layers, int64_t n_nodes, int64
 
 // One reverse-diffusion step on the current stream of `weights`' device.  `post` holds the 5 (categorical) / 5 (gaussian)
 // host-computed posterior constants (include/difusco_hip.h: difusco_step_args.post); `cfg` = {hidden, n_layers,
-// out_channels, task, precision, no_fusion, xt_is_binary, gn_phase}.
+// out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}.
 std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
     int diffusion, const at::Tensor& weights, const at::Tensor& rowptr, const at::Tensor& col,
     const c10::optional<at::Tensor>& perm, const c10::optional<at::Tensor>& row, const c10::optional<at::Tensor>& seg_ptr,
     const c10::optional<at::Tensor>& points, const at::Tensor& xt, double t, c10::ArrayRef<double> post,
     const c10::optional<at::Tensor>& rand, int64_t seed, int64_t offset, at::Tensor workspace, c10::ArrayRef<int64_t> cfg,
     bool want_pred, bool want_prob, const c10::optional<at::Tensor>& gn_sums) {
-  TORCH_CHECK(cfg.size() == 8, "cfg = {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase}");
+  TORCH_CHECK(cfg.size() == 9, "cfg = {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}");
   TORCH_CHECK(post.size() <= 8, "post holds at most 8 constants");
   need(weights, at::kFloat, "weights", true);
   need(rowptr, at::kInt, "rowptr", true);
@@ -128,6 +128,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
   a.precision = (int32_t)cfg[4];
   a.no_fusion = (int32_t)cfg[5];
   a.gn_phase = (int32_t)cfg[7];
+  a.flags = (int32_t)cfg[8];
   a.gn_sums = static_cast<double*>(const_cast<void*>(ptr_or_null(gn_sums)));
   check(difusco_denoise_step(&a), "difusco_denoise_step");
   return {xt_out, pred, prob};
@@ -152,7 +153,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> denoise_step_gaussian(STEP_SIGNAT
 const char* kStepSchema =
     "(Tensor weights, Tensor rowptr, Tensor col, Tensor? perm, Tensor? row, Tensor? seg_ptr, Tensor? points, Tensor xt, "
     "float t, float[] post, Tensor? rand, int seed, int offset, Tensor(a!) workspace, int[] cfg, bool want_pred, "
-    "bool want_prob, Tensor? gn_sums) -> (Tensor, Tensor, Tensor)";
+    "bool want_prob, Tensor(b!)? gn_sums) -> (Tensor, Tensor, Tensor)";
 
 }  // namespace
 

@@ -67,8 +67,8 @@ class BlobEngineConfig(dict):
 
 
 def engine_from_broadcast(state_dict: Optional[dict], device, src: int = 0, group=None, precision: str = "fp16x3",
-                          fused: bool = True):
+                          fused: bool = True, flags: int = 0):
     from .engine import DenoiseEngine
     (hidden, n_layers, out_channels), blob = broadcast_weights(state_dict, device, src, group)
     return DenoiseEngine(BlobEngineConfig.make(hidden, n_layers, out_channels), device=device, blob=blob,
-                         precision=precision, fused=fused)
+                         precision=precision, fused=fused, flags=flags)

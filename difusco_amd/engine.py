@@ -17,7 +17,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class DenoiseEngine:
     def __init__(self, state_dict, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
-                 fused: bool = True, backend: str = "ctypes"):
+                 fused: bool = True, backend: str = "ctypes", flags: int = 0):
         """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
         ``blob``: an already packed blob (e.g. received by RCCL broadcast) instead of packing here."""
         self.device = torch.device(device)
@@ -32,6 +32,7 @@ class DenoiseEngine:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
         self.precision = precision
         self.fused = fused          # fused edge-layer kernel (H == 256, precision bf16x3 / fp16x3)
+        self.flags = int(flags)     # difusco_step_args.flags (_lib.FLAG_*): per-call A/B switches of the fused path
         if backend not in ("ctypes", "torch"):
             raise ValueError("backend must be 'ctypes' (C ABI through ctypes) or 'torch' (torch.ops.difusco custom ops)")
         self.backend = backend
@@ -85,6 +86,8 @@ class DenoiseEngine:
         pred = torch.empty((rows, 2) if C == 2 else (rows,), dtype=torch.float32, device=dev) if want_pred else None
         prob = torch.empty(rows, dtype=torch.float32, device=dev) if (want_prob and C == 2) else None
         ws = self._workspace(g)
+        # the Philox key and offset are 63-bit on both backends (the torch op schema carries signed 64-bit ints)
+        seed, offset = int(seed) & (2 ** 63 - 1), int(offset) & (2 ** 63 - 1)
         if self.backend == "torch":
             return self._step_torch_op(g, task, diffusion, xt, t, post, points, xt_is_binary, rand, seed, offset,
                                        want_pred, want_prob, gn_reduce, ws)
@@ -105,7 +108,7 @@ class DenoiseEngine:
             a.post[i] = float(post[i]) if i < len(post) else 0.0
         a.rand_mode = _lib.RAND_INJECTED if rand is not None else (_lib.RAND_PHILOX if draws else _lib.RAND_NONE)
         a.rand = _ptr(rand)
-        a.seed, a.offset = int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1)
+        a.seed, a.offset = seed, offset
         a.xt_out, a.pred_out, a.prob_out = _ptr(xt_out), _ptr(pred), _ptr(prob)
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
         a.stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -113,6 +116,7 @@ class DenoiseEngine:
         a.no_fusion = 0 if self.fused else 1
         a.row = _ptr(g.row)
         a.gn_phase, a.gn_sums = 0, None
+        a.flags = self.flags
         with torch.cuda.device(dev):
             if gn_reduce is None:
                 _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
@@ -134,10 +138,9 @@ class DenoiseEngine:
         """The same step through ``torch.ops.difusco.denoise_step_{categorical,gaussian}`` (csrc/torch_ops.cpp)."""
         op = self._ops.denoise_step_categorical if diffusion == _lib.CATEGORICAL else self._ops.denoise_step_gaussian
         cfg = [self.hidden, self.n_layers, self.out_channels, task, _lib.PRECISIONS[self.precision], 0 if self.fused else 1,
-               1 if xt_is_binary else 0, 0]
+               1 if xt_is_binary else 0, 0, self.flags]
         seg = g.seg_ptr if g.n_segments > 1 else None
         post = [float(v) for v in post]
-        seed, offset = int(seed) & (2 ** 63 - 1), int(offset) & (2 ** 63 - 1)
 
         def call(phase, sums):
             cfg[7] = phase

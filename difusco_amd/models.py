@@ -44,7 +44,7 @@ class COMetaModel:
 
     def __init__(self, param_args=None, state_dict=None, node_feature_only=False, device="cuda:0",
                  seed: Optional[int] = None, engine: Optional[DenoiseEngine] = None, precision: str = "fp16x3",
-                 fused: bool = True, gn_reduce=None, reorder_nodes: bool = True, backend: str = "ctypes"):
+                 fused: bool = True, gn_reduce=None, reorder_nodes: bool = True, backend: str = "ctypes", flags: int = 0):
         args = dict(_DEFAULTS)
         if param_args is not None:
             args.update(vars(param_args) if not isinstance(param_args, dict) else param_args)
@@ -67,7 +67,7 @@ class COMetaModel:
         if engine is None:
             if state_dict is None:
                 raise ValueError("state_dict (reference GNNEncoder weights) or engine required")
-            engine = DenoiseEngine(state_dict, device=device, precision=precision, fused=fused, backend=backend)
+            engine = DenoiseEngine(state_dict, device=device, precision=precision, fused=fused, backend=backend, flags=flags)
         if engine.out_channels != out_channels:
             raise ValueError(f"weights have {engine.out_channels} output channels, "
                              f"{self.diffusion_type} diffusion needs {out_channels}")
@@ -130,9 +130,9 @@ class COMetaModel:
         table and the table-input first layer are exact only for 0/1 inputs.  The sampling loop feeds our own Bernoulli
         outputs back, which are known without looking (same storage, unmodified); anything else is checked on the
         device (one small reduction + sync per call).  Values whose truncation is not 0/1 raise, like ``one_hot``."""
-        known = self._binary_out
+        known = self._binary_out      # (tensor kept alive, version or None): the storage address is unique while held
         if known is not None and known[0].data_ptr() == xt.data_ptr() and known[0].numel() == xt.numel() \
-                and not xt.is_inference() and known[1] == xt._version:
+                and (known[1] is None) == xt.is_inference() and (known[1] is None or known[1] == xt._version):
             return True
         if bool(((xt == 0) | (xt == 1)).all()):
             return True
@@ -153,7 +153,9 @@ class COMetaModel:
             g, task, _lib.CATEGORICAL, xt, float(t), post, points=points, xt_is_binary=self._xt_is_binary(xt),
             rand=uniform if target_t > 0 else None, seed=self.seed, offset=self._next_offset(),
             want_pred=return_aux, want_prob=return_aux, gn_reduce=self.gn_reduce)
-        self._binary_out = (out, out._version) if (target_t > 0 and not out.is_inference()) else None
+        # tensors created under torch.inference_mode() (Lightning's default for trainer.test) have no version counter:
+        # for those the held reference + storage identity is the whole key (no host sync in the 50-step loop either way)
+        self._binary_out = (out, None if out.is_inference() else out._version) if target_t > 0 else None
         return (out, pred, prob) if return_aux else out
 
     def _gaussian(self, g, task, points, xt, t, target_t, noise, return_aux):

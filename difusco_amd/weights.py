@@ -46,22 +46,63 @@ def _slab_layout(p16: torch.Tensor, n_out: int, k: int) -> torch.Tensor:
     return t.permute(1, 0, 2, 3).contiguous().reshape(-1)
 
 
-def split_planes(w: torch.Tensor) -> torch.Tensor:
+def pow2_scale(maxabs: torch.Tensor) -> torch.Tensor:
+    """Elementwise 2^k (float32) with maxabs * 2^k in [2^14, 2^15); k clamped to [-100, 100] (zero / denormal / huge maxima
+    get the clamp).  The same rule as ``pow2_scale_for`` in csrc/common.h."""
+    m = maxabs.detach().float().abs().reshape(-1)
+    ex = ((m.view(torch.int32) >> 23) & 255).clamp(41, 241)          # biased exponent
+    k = (141 - ex).to(torch.float32)
+    return torch.pow(torch.tensor(2.0), k).reshape(maxabs.shape)
+
+
+def split_planes(w: torch.Tensor, per_row: bool = False) -> torch.Tensor:
     """[n_out, k] fp32 -> five 16-bit planes: bf16 hi | mid | lo, then fp16 hi | lo (all RNE, each the
-    rounding of what the previous planes left), every plane in the slab layout above.  Returned as a
-    flat fp32-typed view (5*n_out*k/2 floats) ready to be copied into the blob."""
+    rounding of what the previous planes left), every plane in the slab layout above, followed by n_out
+    floats: the inverse power-of-two scales of the fp16 planes.
+
+    The fp16 planes are those of ``w * 2^k`` with ``max|w| * 2^k`` in [2^14, 2^15) - one k for the matrix, or one per
+    output row (``per_row``).  fp16 is normal only down to 2^-14: unscaled, the low plane of every ``|w| < 2^-3`` would be
+    a subnormal with an absolute 2^-25 floor instead of 11 further significand bits.  The scale is exact; the kernels
+    multiply the accumulator by the stored ``2^-k`` where they add the bias.  Returned as a flat fp32-typed view
+    (5*n_out*k/2 + n_out floats) ready to be copied into the blob."""
     n_out, k = w.shape
+    w = w.detach().float()
     planes, rest = [], w.clone()
     for _ in range(3):
         p = rest.to(torch.bfloat16)
         rest = rest - p.float()
         planes.append(_slab_layout(p.view(torch.int16), n_out, k))
-    rest = w.clone()
+    if per_row:
+        scale = pow2_scale(w.abs().amax(dim=1, keepdim=True))
+    else:
+        scale = pow2_scale(w.abs().amax().reshape(1, 1)).expand(n_out, 1)
+    rest = w * scale
     for _ in range(2):
         p = rest.to(torch.float16)
         rest = rest - p.float()
         planes.append(_slab_layout(p.view(torch.int16), n_out, k))
-    return torch.cat(planes).view(torch.float32)
+    inv = (1.0 / scale).reshape(-1).contiguous()
+    return torch.cat([torch.cat(planes).view(torch.float32), inv])
+
+
+def plane_scale_inv(planes: torch.Tensor, n_out: int, k: int) -> torch.Tensor:
+    """The n_out inverse fp16 scales stored behind the five planes of ``split_planes``."""
+    return planes[5 * n_out * k // 2: 5 * n_out * k // 2 + n_out]
+
+
+LOG2E = 1.4426950408889634
+
+
+def fused_scales(w_c: torch.Tensor, w_o: torch.Tensor, g_o: torch.Tensor, b_o: torch.Tensor) -> torch.Tensor:
+    """The 8-float operand-scale record of the fused edge kernel (include/difusco_hip.h: DIFUSCO_WL_FUSED_SCALES):
+    {2^-kc, 2^-(ko+ka), 2^ka, -log2(e) 2^-ka, 0...}.  ka comes from a bound that needs no data: the kernel's GEMM 2 operand is
+    a = SiLU(z), z = LN(y) g_o + b_o with |LN(y)| <= sqrt(H - 1) < 16, and |SiLU(z)| <= max(|z|, 0.2785)."""
+    inv_c = 1.0 / pow2_scale(w_c.detach().float().abs().amax().reshape(1))[0]      # the per-matrix scales of split_planes
+    inv_o = 1.0 / pow2_scale(w_o.detach().float().abs().amax().reshape(1))[0]
+    bound = torch.clamp(16.0 * g_o.detach().float().abs().max() + b_o.detach().float().abs().max(), min=0.2785)
+    sa = pow2_scale(bound.reshape(1))[0]
+    nsig = torch.tensor(-LOG2E, dtype=torch.float32) / sa
+    return torch.stack([inv_c, inv_o / sa, sa, nsig] + [torch.tensor(0.0)] * 4).float()
 
 
 def pack_state_dict(state) -> torch.Tensor:
@@ -92,7 +133,10 @@ def pack_state_dict(state) -> torch.Tensor:
             elif name == "@node4.bias":
                 t = torch.cat([state[f"layers.{l}.{m}.bias"] for m in "UVAB"], dim=0)
             elif name == "@planes:@node4.weight":
-                t = split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0))
+                t = split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0), per_row=True)
+            elif name == "@fused_scales":
+                t = fused_scales(state[f"layers.{l}.C.weight"], state[f"per_layer_out.{l}.2.weight"],
+                                 state[f"per_layer_out.{l}.0.weight"], state[f"per_layer_out.{l}.0.bias"])
             else:
                 t = fetch(name.format(l=l))
             put(base + i, t)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 7
+#define DIFUSCO_ABI_VERSION 8
 
 enum {
   DIFUSCO_OK = 0,
@@ -40,7 +40,11 @@ enum {
   DIFUSCO_PREC_FP32 = 0,   /* E-row linears on v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fma chain) */
   DIFUSCO_PREC_BF16X3 = 1, /* 2 bf16 planes, 3 products: ~2^-17 relative per product                    */
   DIFUSCO_PREC_BF16X6 = 2, /* 3 bf16 planes, 6 products: all 24 significand bits, fp32-class accuracy    */
-  DIFUSCO_PREC_FP16X3 = 3  /* 2 fp16 planes, 3 products: 22 significand bits, needs |x| < 65504          */
+  DIFUSCO_PREC_FP16X3 = 3  /* 2 fp16 planes, 3 products, operands pre-scaled by exact powers of two into the upper
+                              binades of fp16 (weights per matrix / per row on the host, activations per row or per
+                              32-edge tile on the device): 22 significand bits for elements within 2^-17 of the
+                              largest element of their scaling group, an absolute floor of 2^-39 of that largest
+                              element below; any finite fp32 operand scale (no |x| < 65504 restriction)            */
 };
 enum {
   DIFUSCO_RAND_NONE = 0,     /* no draw: categorical final step (target_t == 0) or DDIM */
@@ -77,6 +81,7 @@ enum {                       /* per layer l, index = GLOBAL_COUNT + l*LAYER_COUN
   DIFUSCO_WL_OUT_W, DIFUSCO_WL_OUT_B,        /* per_layer_out[l].2 : [H,H],[H]       */
   DIFUSCO_WL_C_PLANES, DIFUSCO_WL_OUT_PLANES, /* split planes of C / per_layer_out[l].2 */
   DIFUSCO_WL_NODE4_PLANES,                    /* split planes of the [4H,H] node linear (U|V|A|B) */
+  DIFUSCO_WL_FUSED_SCALES,                    /* 8 floats: operand scales of the fused edge kernel, see below */
   DIFUSCO_WL_COUNT
 };
 /* "*_PLANES" entries: the [H,H] weight w decomposed on the host into five 16-bit planes
@@ -85,8 +90,17 @@ enum {                       /* per layer l, index = GLOBAL_COUNT + l*LAYER_COUN
  * stored back to back in that order (plane stride H*H elements), each plane laid out
  * [H/16 slabs][H rows][16] with slab position j holding k = 16 s + {0..3, 8..11, 4..7, 12..15}[j]
  * (the order in which an MFMA accumulator feeds the next MFMA, see linear_split.hip).
- * 5*H*H 16-bit elements = 2.5*H*H floats of blob space per matrix.  They feed the split-precision MFMA
- * paths selected by difusco_step_args.precision. */
+ * The fp16 planes are those of the SCALED matrix w[f][:] * 2^k_f, k_f chosen on the host so that the largest scaled
+ * magnitude of the scaling group lies in [2^14, 2^15) (one group per matrix for C / per_layer_out / edge_embed, one per
+ * output row for the node linear); the n_out floats that follow the five planes hold 2^-k_f.  Without the scale the
+ * low plane of any |w| < 2^-3 would be an fp16 subnormal with an absolute 2^-25 floor.  The bf16 planes are unscaled
+ * (bf16 has the fp32 exponent range).
+ * 5*n_out*k 16-bit elements + n_out floats = 2.5*n_out*k + n_out floats of blob space per matrix.  They feed the
+ * split-precision MFMA paths selected by difusco_step_args.precision.
+ * DIFUSCO_WL_FUSED_SCALES = {2^-kc, 2^-(ko+ka), 2^ka, -log2(e) * 2^-ka, 0, 0, 0, 0}: kc / ko the plane scales of C /
+ * per_layer_out[l][2]; 2^ka the scale under which the fused kernel produces the GEMM 2 operand a = SiLU(LN_o(.)), from
+ * the bound |a| <= max(16 max|g_o| + max|b_o|, 0.2785) (|LayerNorm| <= sqrt(H-1) < 16).  difusco_amd/weights.py computes
+ * all of it (fused_scales); the e operand of GEMM 1 is scaled per 32-edge tile on the device. */
 /* Fills offsets[0 .. GLOBAL_COUNT + n_layers*WL_COUNT) (floats from blob start) and *total_floats.
  * Returns the number of entries, or a negative error. */
 int difusco_weights_layout(int hidden, int n_layers, int out_channels,
@@ -164,9 +178,14 @@ typedef struct difusco_step_args {
    * shards (e.g. one all-reduce of 65 doubles).  2: finish the step of the preceding phase-1 call (same arguments,
    * same workspace) with the statistics in gn_sums.  Needs n_segments == 1. */
   int32_t gn_phase;
-  int32_t reserved0;
+  int32_t flags;          /* DIFUSCO_FLAG_*: per-call A/B switches of the fused path (results equal to rounding) */
   double* gn_sums;
 } difusco_step_args;
+
+enum {
+  DIFUSCO_FLAG_NO_L0_FOLD = 1,   /* first layer: write e0 to memory and run the general kernel (no 2-row table fold) */
+  DIFUSCO_FLAG_NO_TAIL_FOLD = 2  /* last layer: general kernel + separate GroupNorm statistics pass over e */
+};
 
 size_t difusco_workspace_bytes(int hidden, int n_layers, int n_nodes, int n_edges, int n_segments);
 
@@ -180,10 +199,13 @@ int difusco_denoise_step(const difusco_step_args* args);
 int difusco_linear_rows(const float* x, const float* w, const float* bias, const float* residual,
                         float* y, int64_t m, int k, int n_out, int64_t ldy, void* stream);
 /* Same contract on the split-precision path: `planes` = the five 16-bit planes of W[n_out,k] in the
- * *_PLANES layout above; precision = DIFUSCO_PREC_BF16X3 | _BF16X6 | _FP16X3.  k == n_out in {64,128,256}. */
+ * *_PLANES layout above (planes + inverse scales); precision = DIFUSCO_PREC_BF16X3 | _BF16X6 | _FP16X3.
+ * k == n_out in {64,128,256}.  row_scale_scratch (device, m floats, or NULL): with FP16X3 the rows of x are scaled
+ * individually by a power of two computed in an extra pass (any finite |x|); NULL skips that pass and then needs
+ * 2^-3 <= |x| < 65504 for the full 22 bits. */
 int difusco_linear_rows_split(const float* x, const void* planes, int precision, const float* bias,
                               const float* residual, float* y, int64_t m, int k, int n_out, int64_t ldy,
-                              void* stream);
+                              float* row_scale_scratch, void* stream);
 
 /* One gated-GCN message-passing pass (gnn_encoder.py:110-135 + :445-448 + per_layer_out LN/SiLU):
  *   e' = Ah[j]+Bh[i]+Ce ; h[i] += ReLU(LN_h(Uh[i] + sum_j sigmoid(e')*Vh[j])) (+tbias, MIS)
@@ -202,14 +224,15 @@ int difusco_edge_gate_aggregate(int hidden, int n_nodes, const int32_t* rowptr, 
  * tiles of 8192 floats ordered [f/16][(f/8)%2][((f/4)%2)*32 + s%32][f%4] (csrc/kernels.h edge_tiled_offset,
  * difusco_amd.graph.to_tiled) - every wavefront access is then one contiguous KiB.
  * planes_c / planes_o: the five 16-bit planes of C / per_layer_out[l][2] (see *_PLANES above);
- * precision = DIFUSCO_PREC_BF16X3 | DIFUSCO_PREC_FP16X3.  scratch: >= difusco_fused_scratch_bytes(). */
+ * precision = DIFUSCO_PREC_BF16X3 | DIFUSCO_PREC_FP16X3.  scales: the layer's DIFUSCO_WL_FUSED_SCALES record (device,
+ * 8 floats; required for FP16X3, ignored for BF16X3).  scratch: >= difusco_fused_scratch_bytes(). */
 size_t difusco_fused_scratch_bytes(int n_nodes, int n_edges);
 int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int32_t* rowptr, const int32_t* row,
                              const int32_t* col, const float* node4, float* e, float* h, const void* planes_c,
                              const void* planes_o, const float* b_c, const float* norm_h_w, const float* norm_h_b,
                              const float* norm_e_w, const float* norm_e_b, const float* out_ln_w,
                              const float* out_ln_b, const float* b_out, const float* tbias, int time_on_edge,
-                             void* scratch, void* stream);
+                             const float* scales, void* scratch, void* stream);
 
 /* Elementwise posteriors on already computed predictions (pl_meta_model.py:102-175). */
 int difusco_categorical_posterior(const float* logits, const float* xt, const float* post,
@@ -277,21 +300,20 @@ int difusco_tsp_two_opt(int n_nodes, int batch, const double* points, int32_t* t
  * collect() synchronises, fills ms[c] / launches[c] for c < 5, re-arms, returns brackets read. */
 #define DIFUSCO_PROFILE_CATEGORIES 5
 int difusco_profile_enable(int on, int max_launches);
-/* Profiling knobs, never used in production.  key 0: ablation mask of the fused edge-layer kernel
- * (bit0 skip neighbour-table gathers, bit1 skip the neighbour sum, bit2 skip LN/activation math,
- * bit3 skip GEMM 2) - results are WRONG with a non-zero mask; only kernel time is meaningful. */
-int difusco_debug_set(int key, int value);   /* key 3: 0 = do not
-                                              * fold the first layer's table lookup into the fused kernel (A/B);
-                                              * key 4: 0 = head statistics by a separate pass over e (A/B);
-                                              * key 6: extra dynamic LDS bytes for the fused kernel (occupancy probe);
-                                              * key 7: 0 = fused kernel without its scheduling options (XCD-contiguous
-                                              * tile ranges, alternating MFMA chains, non-temporal e stream, two-stage e
-                                              * prefetch, split LayerNorm reductions) for A/B; non-zero = production;
-                                              * key 8: k steps of load lookahead in the node-row linear (1 or 4; A/B) */
-/* key 1: device buffer [n_tiles][8] of uint64 receiving s_memtime stamps of the fused kernel's phases
- * (NULL disables; profiling only). */
-int difusco_debug_set_ptr(int key, void* p);
 int difusco_profile_collect(double* ms, int64_t* launches, int n_categories);
+
+#ifdef DIFUSCO_PROFILING
+/* Profiling library only (libdifusco_hip_prof.so, built with -DDIFUSCO_PROFILING; `python -m difusco_amd.build --prof`):
+ * process-wide knobs that select timing-only variants of the fused edge-layer kernel.  The production library does
+ * not export these symbols and holds no such state.
+ * key 0: compile-time ablation mask (bit0 skip neighbour-table gathers, bit1 skip the neighbour sum, bit2 skip
+ *        LN/activation math, bit3 skip GEMM 2, 16 = production code + phase stamps ...): results are WRONG by design;
+ * key 6: extra dynamic LDS bytes (occupancy probe);  key 7: A/B variant of the scheduling options (OPT bits);
+ * key 8: k steps of load lookahead in the node-row linear (1 or 4). */
+int difusco_debug_set(int key, int value);
+/* key 1: device buffer [n_tiles][16] of uint64 receiving s_memtime stamps of the fused kernel's phases (NULL disables) */
+int difusco_debug_set_ptr(int key, void* p);
+#endif
 
 #ifdef __cplusplus
 }

@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """Micro-benchmark of the fused edge-layer kernel (+ node finalize) at the bench workload size, with the
-profiling-only ablation masks of difusco_debug_set(0, mask).  GPU only."""
+profiling-only ablation masks of difusco_debug_set(0, mask).  GPU only; loads the PROFILING library
+(libdifusco_hip_prof.so, `python -m difusco_amd.build --prof`)."""
 import ctypes
 import sys
 import os
 import numpy as np
 import torch
+
+os.environ["DIFUSCO_PROFILING_LIB"] = "1"
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from difusco_amd import _lib, graph, synthetic, weights  # noqa: E402
@@ -31,6 +34,7 @@ Wo = ((torch.rand(H, H, generator=gen) * 2 - 1) / 16)
 pc, po = weights.split_planes(Wc).to(dev), weights.split_planes(Wo).to(dev)
 vec = [torch.randn(H, generator=gen).to(dev) * 0.1 for _ in range(4)] + [(1 + 0.1 * torch.randn(H, generator=gen)).to(dev) for _ in range(3)]
 bc, bo, tb, bh, gh, ge, go = vec[0], vec[1], vec[2], vec[3], vec[4], vec[5], vec[6]
+scales = weights.fused_scales(Wc, Wo, go.cpu(), bh.cpu()).to(dev)
 scratch = torch.zeros(_lib.lib().difusco_fused_scratch_bytes(N, E), dtype=torch.uint8, device=dev)
 L = _lib.lib()
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -40,7 +44,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 def run(e, h):
     _lib.check(L.difusco_edge_layer_fused(_lib.PRECISIONS[prec], N, E, P(g.rowptr), P(g.row), P(g.col), P(node4), P(e), P(h),
                                           P(pc), P(po), P(bc), P(gh), P(bh), P(ge), P(bh), P(go), P(bh), P(bo), P(tb), 1,
-                                          P(scratch), st))
+                                          P(scales), P(scratch), st))
 
 
 # interleaved rounds (variants alternate inside one process; report median and min - cdna guide rule 24)

@@ -95,17 +95,41 @@ def test_linear_rows_split(dev, L, prec, tol, m, k):
     planes = weights.split_planes(w).to(dev)
     xd, bd, rd = x.to(dev), b.to(dev), r.to(dev)
     y = torch.full((m, k), float("nan"), device=dev)
-    L.check(L.lib().difusco_linear_rows_split(_p(xd), _p(planes), L.PRECISIONS[prec], _p(bd), _p(rd), _p(y), m, k, k, k, _stream()))
+    rs = torch.empty(m, device=dev)       # scratch for the per-row operand scales of the fp16 path
+    L.check(L.lib().difusco_linear_rows_split(_p(xd), _p(planes), L.PRECISIONS[prec], _p(bd), _p(rd), _p(y), m, k, k, k, _p(rs), _stream()))
     torch.cuda.synchronize()
     err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     print(f"{prec} m={m} k={k}: rel err {err:.2e}")
     assert err < tol, err
     # in place residual (Y == residual), no bias
     ed = r.to(dev)
-    L.check(L.lib().difusco_linear_rows_split(_p(xd), _p(planes), L.PRECISIONS[prec], None, _p(ed), _p(ed), m, k, k, k, _stream()))
+    L.check(L.lib().difusco_linear_rows_split(_p(xd), _p(planes), L.PRECISIONS[prec], None, _p(ed), _p(ed), m, k, k, k, None, _stream()))
     torch.cuda.synchronize()
     ref2 = x.double() @ w.double().t() + r.double()
     assert (ed.cpu().double() - ref2).abs().max().item() / ref2.abs().max().item() < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("fp16x3", 1.5e-6), ("bf16x6", 1.5e-6), ("bf16x3", 2e-5)])   # observed 5-8e-7 / 7-8e-7 / ~1e-5 at EVERY scale
+@pytest.mark.parametrize("wexp,xexp", [(5, 8), (-4, 0), (-10, -8), (-13, 0), (-20, 12), (-30, 30), (-60, -40), (30, 40)])
+def test_linear_rows_split_any_operand_scale(dev, L, prec, tol, wexp, xexp):
+    """fp32 semantics at every operand scale (train.py:114: the reference computes in true fp32 whatever the weights look
+    like): weights ~2^wexp, rows of x ~2^xexp with a 2^+-6 spread between rows, error relative to max|Y| vs fp64.  The
+    fp16 planes only reach this through the power-of-two pre-scaling (weights.split_planes, row scales on the device)."""
+    from difusco_amd import weights
+    g = torch.Generator().manual_seed(wexp * 31 + xexp)
+    m, k = 333, 256
+    x = torch.randn(m, k, generator=g) * 2.0 ** xexp * (2.0 ** torch.randint(-6, 7, (m, 1), generator=g).float())
+    w = (torch.rand(k, k, generator=g) * 2 - 1) * 2.0 ** wexp
+    ref = x.double() @ w.double().t()
+    planes = weights.split_planes(w).to(dev)
+    xd, rs = x.to(dev), torch.empty(m, device=dev)
+    y = torch.full((m, k), float("nan"), device=dev)
+    L.check(L.lib().difusco_linear_rows_split(_p(xd), _p(planes), L.PRECISIONS[prec], None, None, _p(y), m, k, k, k, _p(rs), _stream()))
+    torch.cuda.synchronize()
+    rowmax = ref.abs().amax(dim=1, keepdim=True)
+    err = ((y.cpu().double() - ref).abs() / rowmax).max().item()          # per row: every row keeps fp32-class accuracy
+    print(f"{prec} w~2^{wexp} x~2^{xexp}: rel err {err:.2e}")
+    assert err < tol, err
 
 
 def test_linear_rows_rejects_bad_shapes(L, dev):
@@ -156,7 +180,9 @@ def test_edge_gate_aggregate(dev, L, H, time_on_edge):
     assert (ce_d.cpu() - act_ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("prec,tol", [("fp16x3", 3e-5), ("bf16x3", 3e-4)])
+# tolerances relative to |e| ~ 10 (x10 below): fp16x3 3e-5; bf16x3 (NOT the default; ~2^-17 per product by construction,
+# DESIGN 4.1) 1e-4 - north_star's bound on the step outputs, observed 2-4e-5 here
+@pytest.mark.parametrize("prec,tol", [("fp16x3", 3e-5), ("bf16x3", 1e-4)])
 @pytest.mark.parametrize("time_on_edge", [1, 0])
 @pytest.mark.parametrize("n,p_edge,seed", [(150, 0.35, 0), (64, 0.9, 1), (300, 0.02, 2)])
 def test_edge_layer_fused(dev, L, prec, tol, time_on_edge, n, p_edge, seed):
@@ -197,6 +223,7 @@ def test_edge_layer_fused(dev, L, prec, tol, time_on_edge, n, p_edge, seed):
     d = lambda t: t.to(dev).contiguous()
     e_d, h_d, n4_d = graph.to_tiled(d(e)), d(h), d(node4)      # the fused kernel keeps e in the tiled layout
     pc, po = d(weights.split_planes(Wc)), d(weights.split_planes(Wo))
+    sc_d = d(weights.fused_scales(Wc, Wo, prm[4], prm[5]))
     bc_d, bo_d, tb_d = d(bc), d(bo), d(tb)
     prm_d = [d(t) for t in prm]
     rp_d, row_d, col_d = d(torch.from_numpy(rowptr)), d(torch.from_numpy(row)), d(torch.from_numpy(col))
@@ -204,7 +231,7 @@ def test_edge_layer_fused(dev, L, prec, tol, time_on_edge, n, p_edge, seed):
     L.check(L.lib().difusco_edge_layer_fused(L.PRECISIONS[prec], n, E, _p(rp_d), _p(row_d), _p(col_d), _p(n4_d), _p(e_d),
                                              _p(h_d), _p(pc), _p(po), _p(bc_d), _p(prm_d[0]), _p(prm_d[1]), _p(prm_d[2]),
                                              _p(prm_d[3]), _p(prm_d[4]), _p(prm_d[5]), _p(bo_d), _p(tb_d), time_on_edge,
-                                             _p(scratch), _stream()))
+                                             _p(sc_d), _p(scratch), _stream()))
     torch.cuda.synchronize()
     err_e = (graph.from_tiled(e_d, E).cpu() - e_ref).abs().max().item()
     err_h = (h_d.cpu() - h_ref).abs().max().item()
@@ -897,6 +924,76 @@ def test_bench_workload_tsp500_x16_and_mis_x16(dev):
     assert torch.equal(a, b) and torch.equal(la, lb) and torch.isfinite(la).all() and set(a.unique().tolist()) <= {0.0, 1.0}
     print(f"MIS x16 ({off} nodes, {ei.shape[1]} edges): fused vs unfused logits L_inf {(la - lc).abs().max().item():.3e}")
     assert (la - lc).abs().max().item() < 5e-5
+
+
+def _scaled_params(p, groups, factor, n_layers):
+    """A copy of the oracle parameter dict with the named groups of every layer multiplied by `factor` (weights AND biases)."""
+    q = {k: v.clone() for k, v in p.items()}
+    names = {"abc": ["layers.{l}.A", "layers.{l}.B", "layers.{l}.C"], "uv": ["layers.{l}.U", "layers.{l}.V"],
+             "out": ["per_layer_out.{l}.2"], "ln_o": ["per_layer_out.{l}.0"], "edge_embed": ["edge_embed"],
+             "node_embed": ["node_embed"]}
+    for grp in groups:
+        for nm in names[grp]:
+            for l in (range(n_layers) if "{l}" in nm else [0]):
+                for part in ("weight", "bias"):
+                    q[nm.format(l=l) + "." + part] = q[nm.format(l=l) + "." + part] * factor
+    return q
+
+
+_SCALE_CASES = [(("abc",), -13), (("abc",), -10), (("abc",), -6), (("abc",), 5), (("uv",), -13), (("uv",), 5),
+                (("out",), -13), (("out",), -10), (("out",), 5), (("abc", "uv", "out"), -10), (("abc", "uv", "out"), 4),
+                (("edge_embed",), -8), (("edge_embed",), 8), (("ln_o",), -12), (("ln_o",), 6), (("node_embed",), -9),
+                (("node_embed", "edge_embed"), 10)]
+
+
+@pytest.mark.parametrize("groups,exp", _SCALE_CASES)
+@pytest.mark.parametrize("kind", ["tsp_categorical", "tsp_gaussian", "mis_categorical"])
+def test_default_engine_at_adversarial_weight_scales(dev, kind, groups, exp):
+    """fp32 semantics at every operand scale.  The reference computes in true fp32 whatever the weights
+    look like (train.py:114; trained checkpoints are external, and per_layer_out[*][2] STARTS at zero,
+    gnn_encoder.py:339-347), so the default engine (fused kernel, fp16x3 planes) is compared with the fp32 oracle with
+    whole parameter groups multiplied by 2^exp: A/B/C, U/V, per_layer_out, the output LayerNorm affine, the embeddings.
+    Round 2's unscaled planes gave logits L_inf 2.9e-4 at A/B/C x 2^-10 and 1.1e-3 at x 2^-13 (emulation in VERDICT.md);
+    with the power-of-two operand scaling every case sits at the default-scale error.  One 12-layer step, H = 256."""
+    from difusco_amd import MISModel, TSPModel
+    H, Lyr = 256, 12
+    C = 1 if kind == "tsp_gaussian" else 2
+    p = _scaled_params(O.init_params(H, Lyr, C, seed=77), groups, 2.0 ** exp, Lyr)
+    g = torch.Generator().manual_seed(7)
+    t, tt = 500, 469
+    if kind == "mis_categorical":
+        ei = torch.from_numpy(O.er_mis_instance(120, 0.12, seed=3))
+        xt = (torch.randn(120, generator=g) > 0).float()
+        u = torch.rand(120, generator=g)
+        _, ref, ref_prob = O.mis_categorical_denoise_step(p, O.CategoricalTables(), xt, t, ei, tt, uniform=u, return_aux=True)
+        m = MISModel(_args("categorical", -1, H=H, L=Lyr), p, device=dev)
+        _, out, prob = m.categorical_denoise_step(xt.to(dev), np.array([t]), dev, ei.to(dev), target_t=np.array([tt]),
+                                                  uniform=u, return_aux=True)
+    else:
+        pts, ei = O.tsp_instance(60, 10, seed=4)
+        pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
+        if kind == "tsp_categorical":
+            xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
+            u = torch.rand(ei.shape[1], generator=g)
+            _, ref, ref_prob = O.tsp_categorical_denoise_step(p, O.CategoricalTables(), pts, xt, t, ei, tt, uniform=u,
+                                                              return_aux=True)
+            m = TSPModel(_args("categorical", 10, H=H, L=Lyr), p, device=dev)
+            _, out, prob = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev),
+                                                      target_t=np.array([tt]), uniform=u, return_aux=True)
+        else:
+            xt = torch.randn(ei.shape[1], generator=g)
+            ref_x, ref = O.tsp_gaussian_denoise_step(p, O.GaussianTables(), pts, xt, t, ei, tt, return_aux=True)
+            m = TSPModel(_args("gaussian", 10, H=H, L=Lyr), p, device=dev)
+            out_x, out = m.gaussian_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev),
+                                                 target_t=np.array([tt]), return_aux=True)
+            prob = ref_prob = None
+            assert (out_x.cpu() - ref_x).abs().max().item() < TOL
+    assert torch.isfinite(out).all()
+    err = (out.cpu().reshape(ref.shape) - ref).abs().max().item()
+    print(f"{kind} {'+'.join(groups)} x 2^{exp}: network output L_inf {err:.2e} (|ref| max {ref.abs().max().item():.2e})")
+    assert err < TOL, err
+    if prob is not None:
+        assert (prob.cpu().reshape(-1) - ref_prob.reshape(-1)).abs().max().item() < TOL
 
 
 @pytest.mark.parametrize("task", ["tsp", "mis"])
