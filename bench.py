@@ -186,6 +186,9 @@ def main():
                     help="A/B: k steps of global-load lookahead in the node-row linear (difusco_debug_set key 8)")
     ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE",
                     help="profiling library only: difusco_debug_set(KEY, VALUE) before the run (repeatable)")
+    ap.add_argument("--streams", type=int, default=1, help="EXPERIMENT: split the rank's graphs into this many groups, each "
+                    "stepped by its own engine on its own HIP stream (TSP workloads), so that one group's small node kernels "
+                    "and launch tails overlap another group's edge kernels")
     ap.add_argument("--prof-lib", action="store_true", help="load libdifusco_hip_prof.so (profiling build) instead of the "
                     "production library")
     ap.add_argument("--no-node-reorder", action="store_true", help="A/B: keep the caller's node numbering (no Morton order)")
@@ -321,6 +324,35 @@ def main():
             return mdl.gaussian_denoise_step(points, xt, t1, device, edge_index, target_t=t2)
         return mdl.categorical_denoise_step(points, xt, t1, device, edge_index, target_t=t2)
 
+    groups = None
+    if args.streams > 1 and not dry and not mis:
+        # experiment: S independent sub-batches on S streams.  Each group is its own call (its own head statistics).
+        groups = []
+        per = (hi - lo) // args.streams
+        assert per * args.streams == hi - lo, "--streams must divide the graphs per GPU"
+        for k in range(args.streams):
+            eng_k = DenoiseEngine(params, device=device, blob=engine.blob, precision=args.precision, fused=not args.no_fusion,
+                                  flags=step_flags)
+            m_k = TSPModel(margs, engine=eng_k, seed=1234 + rank + 100 * k, reorder_nodes=not args.no_node_reorder)
+            p_k, e_k = tsp_batch_gpu(args.nodes, args.knn, range(lo + k * per, lo + (k + 1) * per), device)
+            x_k = torch.randn(e_k.shape[1], generator=gen)
+            x_k = (x_k if gaussian else (x_k > 0).float()).to(device)
+            groups.append(dict(model=m_k, points=p_k, ei=e_k, xt=x_k, stream=torch.cuda.Stream(device=device)))
+        base_one_step = one_step
+
+        def one_step(i, xt, mdl=None):      # noqa: F811
+            if mdl is not None:
+                return base_one_step(i, xt, mdl)
+            t1, t2 = sched(i % 49)
+            t1, t2 = np.array([t1]), np.array([t2])
+            for gk in groups:      # no cross-stream waits: the groups are independent chains, fenced by device syncs
+                with torch.cuda.stream(gk["stream"]):
+                    if gaussian:
+                        gk["xt"] = gk["model"].gaussian_denoise_step(gk["points"], gk["xt"], t1, device, gk["ei"], target_t=t2)
+                    else:
+                        gk["xt"] = gk["model"].categorical_denoise_step(gk["points"], gk["xt"], t1, device, gk["ei"], target_t=t2)
+            return xt
+
     def fence():
         if not dry:
             torch.cuda.synchronize(device)
@@ -372,7 +404,7 @@ def main():
                        "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision,
                        "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3"),
                        "node_order": "caller" if (args.no_node_reorder or mis) else "morton per graph (graph.py)",
-                       "fused_opt": args.fused_opt, "debug_set": args.debug_set or None},
+                       "fused_opt": args.fused_opt, "debug_set": args.debug_set or None, "streams": args.streams},
         }
         if prof is not None and prof["launches"][0] > 0:
             n_lin = prof["launches"][0]

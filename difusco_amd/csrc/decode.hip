@@ -11,8 +11,8 @@
 //           2. per pair: S = fl32(A_ij + A_ji) (the reference adds the two float32 matrices, tsp_utils.py:108-114),
 //              score = double(S) / ||p_i - p_j||_2 in float64 (cython_merge.pyx:21,37), self loops set aside;
 //           3. stable radix sort by score, descending (ties keep flat-index order);
-//   host    4. the reference's route_begin / route_end bookkeeping over the sorted pairs (cython_merge.pyx:46-96),
-//              closing edge, and the walk from node 0 that always takes the larger unvisited neighbour
+//   host    4. greedy insertion over the sorted pairs with the reference's accept / reject decisions
+//              (cython_merge.pyx:46-96), kept as path end points + node degrees, the closing edge, and the walk from node 0 that always takes the larger unvisited neighbour
 //              (tsp_utils.py:134-141).
 //
 // `merge_iterations` reproduces the reference's count over its dense list: the self entries (score -inf, sorted
@@ -124,18 +124,6 @@ hipError_t carve(void* base, long long E, Carve* c) {
   return hipSuccess;
 }
 
-// cython_merge.pyx:107-120 (path compression included)
-int find_root(std::vector<int>& link, int i) {
-  int r = i;
-  while (link[r] != r) r = link[r];
-  while (link[i] != r) {
-    const int nx = link[i];
-    link[i] = r;
-    i = nx;
-  }
-  return r;
-}
-
 int merge_one_sample(const Carve& c, int n_nodes, long long E, const float* heat, const float* points, hipStream_t st,
                      int32_t* tour_out, int64_t* merge_iterations, int32_t* completed);
 
@@ -230,9 +218,13 @@ int merge_one_sample(const Carve& c, int n_nodes, long long E, const float* heat
     if (er != hipSuccess) return set_error(DIFUSCO_EHIP, "sorted pairs: %s", hipGetErrorString(er));
   }
 
-  // ---- host: greedy insertion (cython_merge.pyx:26-104) -------------------------------------------------
-  std::vector<int> route_begin(N), route_end(N), nb0(N, -1), nb1(N, -1);
-  for (int v = 0; v < n_nodes; ++v) route_begin[v] = route_end[v] = v;
+  // ---- host: greedy insertion (the accept / reject rule of cython_merge.pyx:26-104) --------------------------
+  // The partial tour is a set of vertex-disjoint paths.  A candidate pair (i, j) is accepted iff both nodes still have a free
+  // side and they are not the two ends of one path (that would close a cycle early) - the same decisions as the reference's
+  // two union-find forests over route begins / ends, kept here as one array over path END POINTS: far_end[v] is the other
+  // end of the path v terminates (v itself while v is isolated; stale and never read once v is interior).
+  std::vector<int> far_end(N), degree(N, 0), nb0(N, -1), nb1(N, -1);
+  for (int v = 0; v < n_nodes; ++v) far_end[v] = v;
   auto link_nodes = [&](int a, int b) {
     (nb0[a] < 0 ? nb0[a] : nb1[a]) = b;
     (nb0[b] < 0 ? nb0[b] : nb1[b]) = a;
@@ -240,32 +232,14 @@ int merge_one_sample(const Carve& c, int n_nodes, long long E, const float* heat
   long long merge_count = 0, iterations = counters[1];   // the -inf self entries come first in the dense order
   int within = 0;
   auto try_insert = [&](int i, int j) -> bool {
-    const int begin_i = find_root(route_begin, i), end_i = find_root(route_end, i);
-    const int begin_j = find_root(route_begin, j), end_j = find_root(route_end, j);
-    if (begin_i == begin_j) return false;
-    if (i != begin_i && i != end_i) return false;
-    if (j != begin_j && j != end_j) return false;
+    if (degree[i] == 2 || degree[j] == 2 || far_end[i] == j) return false;
+    const int tail_i = far_end[i], tail_j = far_end[j];   // the joined path runs tail_i .. i - j .. tail_j
+    far_end[tail_i] = tail_j;
+    far_end[tail_j] = tail_i;
+    ++degree[i];
+    ++degree[j];
     link_nodes(i, j);
     ++merge_count;
-    if (i == begin_i && j == end_j) {
-      route_begin[begin_i] = begin_j;
-      route_end[end_j] = end_i;
-    } else if (i == end_i && j == begin_j) {
-      route_begin[begin_j] = begin_i;
-      route_end[end_i] = end_j;
-    } else if (i == begin_i && j == begin_j) {
-      route_begin[begin_i] = end_j;
-      route_begin[begin_j] = end_j;
-      route_begin[end_j] = end_j;
-      route_end[end_j] = end_i;
-      route_end[begin_j] = end_i;
-    } else {   // i == end_i && j == end_j
-      route_end[end_i] = begin_j;
-      route_begin[begin_j] = begin_i;
-      route_begin[end_j] = begin_i;
-      route_end[end_j] = begin_j;
-      route_end[begin_j] = begin_j;
-    }
     return true;
   };
   size_t k = 0;
@@ -303,8 +277,9 @@ int merge_one_sample(const Carve& c, int n_nodes, long long E, const float* heat
     }
   }
   if (merge_count != N - 1) return set_error(DIFUSCO_EINVAL, "tsp_merge_tour: could not assemble a Hamiltonian path");
-  const int final_begin = find_root(route_begin, 0), final_end = find_root(route_end, 0);
-  link_nodes(final_end, final_begin);
+  int open_end = 0;                                     // one end of the Hamiltonian path; far_end gives the other
+  while (open_end < n_nodes && degree[open_end] == 2) ++open_end;
+  link_nodes(far_end[open_end], open_end);
   // tsp_utils.py:134-141: walk from node 0, always to the larger-numbered neighbour that is not the previous node
   tour_out[0] = 0;
   int prev = -1, cur = 0;

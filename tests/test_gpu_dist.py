@@ -1,0 +1,90 @@
+"""RCCL on the hardware that is there: the `nccl` code path bench.py takes at N > 1 - process group with a
+device id, packed-blob broadcast, the 65-double statistics all-reduce around a two-phase step - with world size 1, in a
+child process (a process group is process-wide state).  And: `--gpus 1` under torch.distributed.run prints the same JSON
+keys as the plain run, so the N = 1 line of a scaling sweep is the default bench line by construction."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["DIFUSCO_ROOT"])
+from difusco_amd.dist import engine_from_broadcast, gn_allreduce
+from difusco_amd.models import TSPModel
+from difusco_amd.synthetic import random_state_dict, tsp_batch_gpu
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)      # "nccl" is RCCL on ROCm
+assert dist.get_backend() == "nccl"
+params = random_state_dict(256, 3, 2, seed=5)
+engine = engine_from_broadcast(params, dev, src=0)                                  # RCCL broadcast of the packed blob
+t = torch.arange(65, dtype=torch.float64, device=dev)
+red = gn_allreduce()
+red(t)                                                                              # RCCL all-reduce on a GPU tensor
+assert torch.equal(t.cpu(), torch.arange(65, dtype=torch.float64))
+args = dict(diffusion_type="categorical", sparse_factor=10, n_layers=3, hidden_dim=256)
+pts, ei = tsp_batch_gpu(64, 10, range(2), dev)
+g = torch.Generator().manual_seed(1)
+xt = (torch.randn(ei.shape[1], generator=g) > 0).float().to(dev)
+u = torch.rand(ei.shape[1], generator=g)
+m_red = TSPModel(args, engine=engine, seed=7, gn_reduce=red)                       # two-phase step around the all-reduce
+m_one = TSPModel(args, engine=engine, seed=7)
+a = m_red.categorical_denoise_step(pts, xt, np.array([500]), dev, ei, target_t=np.array([470]), uniform=u, return_aux=True)
+b = m_one.categorical_denoise_step(pts, xt, np.array([500]), dev, ei, target_t=np.array([470]), uniform=u, return_aux=True)
+torch.cuda.synchronize()
+assert torch.isfinite(a[1]).all()
+# one shard: the summed statistics ARE this call's statistics
+assert (a[1] - b[1]).abs().max().item() < 1e-5 and torch.equal(a[0], b[0])
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _env(port):
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", DIFUSCO_ROOT=ROOT)
+    return env
+
+
+def test_rccl_world_size_one_broadcast_allreduce_two_phase_step():
+    res = subprocess.run([sys.executable, "-c", _CHILD], env=_env(_free_port()), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "RCCL_WORLD1_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+def test_bench_gpus_1_under_torchrun_prints_the_plain_run_keys():
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-steps", "0", "--no-exact-fp32", "--graphs-per-gpu", "2",
+              "--nodes", "200", "--knn", "20"]
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600,
+                           cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    port = _free_port()
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + common,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-3000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert set(a) == set(b) and set(a["config"]) == set(b["config"]) and set(a["roofline"]) == set(b["roofline"])
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["config"] == b["config"]
+    assert 0.5 < a["value"] / b["value"] < 2.0

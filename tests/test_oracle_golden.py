@@ -237,3 +237,33 @@ def test_h256_sparse_mis():
     _check_cat_steps(z, 3, lambda xt, t, tt, u: O.mis_categorical_denoise_step(cat, tab, xt, t, ei, tt, uniform=u,
                                                                                return_aux=True))
     _check_gau_steps(z, 2, lambda xt, t, tt: O.mis_gaussian_denoise_step(gau, gt, xt, t, ei, tt, return_aux=True))
+
+
+def test_tsp50_dense_full_width_full_length(golden_dir):
+    """configs[0] of BASELINE.json pinned end to end on PURE reference arithmetic (tier B, no substitute code anywhere):
+    TSP-50 dense categorical, H=256, 12 layers, all 50 cosine steps of test_step (pl_tsp_model.py:185-222).  The oracle is
+    teacher-forced with the reference's own x_t of every step."""
+    import os
+    z = np.load(os.path.join(golden_dir, "tsp50_dense_h256_l12_50steps.npz"))
+    assert "none executed" in str(z["provenance"])
+    p = O.init_params(int(z["hidden"]), int(z["n_layers"]), 2, seed=int(z["seed"]))
+    assert O.params_sha256(p) == str(z["sha"])
+    pts, tab = torch.from_numpy(z["points"]), O.CategoricalTables()
+    worst_l = worst_p = 0.0
+    for i in range(int(z["steps"])):
+        t, tt = (int(v) for v in z["t"][i])
+        assert (t, tt) == tuple(O.inference_schedule("cosine", 1000, 50, i))
+        xt = torch.from_numpy(z["xt_in"][i]).float()
+        u = torch.from_numpy(z["uniform"][i]) if tt > 0 else None
+        out, logits, prob = O.tsp_categorical_denoise_step(p, tab, pts, xt, t, None, tt, uniform=u, return_aux=True)
+        worst_l = max(worst_l, float(np.abs(logits.numpy() - z["logits"][i]).max()))      # both [B,C,V,V]
+        if tt > 0:
+            worst_p = max(worst_p, float(np.abs(prob.numpy().reshape(-1) - z["prob"][i].reshape(-1)).max()))
+            safe = np.abs(z["uniform"][i].reshape(-1) - z["prob"][i].reshape(-1)) > 1e-5
+            np.testing.assert_array_equal(out.numpy().reshape(-1)[safe], z["out"][i].reshape(-1)[safe])
+            if i + 1 < int(z["steps"]):       # the fixture is the reference's own free-running chain
+                np.testing.assert_array_equal(z["out"][i].astype(np.int8), z["xt_in"][i + 1])
+        else:
+            np.testing.assert_allclose(out.numpy().reshape(-1), z["out"][i].reshape(-1), rtol=0, atol=2e-5)
+    print(f"TSP-50 dense 50 steps, oracle vs imported reference: logits L_inf {worst_l:.2e}, prob L_inf {worst_p:.2e}")
+    assert worst_l < 2e-5 and worst_p < 2e-5
