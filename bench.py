@@ -70,9 +70,10 @@ def oracle_threads():
     return max(1, min(32, phys))
 
 
-def cpu_baseline(wl, steps, params, gpu_model, device):
+def cpu_baseline(wl, steps, params, gpu_model, device, warm=True):
     """The CPU oracle (port of the reference op sequence, incl. V applied on E gathered rows) on a bounded
-    sample: ONE graph of the same workload, 1 warm-up + `steps` timed denoise steps, torch threads = oracle_threads()
+    sample: ONE graph of the same workload, 1 warm-up (`warm`; skipped for the minute-long TSP-10000 step) + `steps` timed
+    denoise steps, torch threads = oracle_threads()
     (the default, one thread per SMT sibling, oversubscribes the GEMMs 2.5x).  The first timed step is also run on the GPU
     (same graph, same x_t, same injected uniforms, default engine) and the network outputs are compared:
     "parity_linf".  This leg is the only place where bench.py touches oracle/."""
@@ -115,7 +116,8 @@ def cpu_baseline(wl, steps, params, gpu_model, device):
                                                                return_aux=True)
     parity = {}
     with torch.no_grad():
-        xt = step(xt, 1000, 969, **({} if u is None else {"generator": g}))       # warm-up
+        if warm:
+            xt = step(xt, 1000, 969, **({} if u is None else {"generator": g}))       # warm-up
         t0 = time.perf_counter()
         for i in range(steps):
             t1, t2 = O.inference_schedule("cosine", 1000, 50, i + 1)
@@ -139,7 +141,7 @@ def cpu_baseline(wl, steps, params, gpu_model, device):
         dt = time.perf_counter() - t0
     torch.set_num_threads(prev_threads)
     out = {"value": steps / dt, "unit": "graph-steps/s", "cores": cores, "kind": "port",
-           "sample": f"{what} H={H} L={LAYERS} fp32 {wl['diffusion']}, 1 warm-up + {steps} timed steps "
+           "sample": f"{what} H={H} L={LAYERS} fp32 {wl['diffusion']}, {'1 warm-up + ' if warm else 'no warm-up, '}{steps} timed step(s) "
                      f"of the CPU oracle ({dt:.1f} s, incl. one GPU step for the parity check), "
                      f"torch.set_num_threads({cores}) (fastest of 16/32/64/128 on this host class, profiles/r02/cpu_threads_scan.txt)"}
     out.update(parity)
@@ -196,13 +198,10 @@ def main():
     ap.add_argument("--precision", default="fp16x3", choices=["fp32", "bf16x3", "bf16x6", "fp16x3"],
                     help="arithmetic of the E-row linears: exact fp32 MFMA, or fp32 split into 2/3 bf16 planes "
                          "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` sub-record (the other north_star sizes: "
+                    "tsp500, tsp10000, mis - a few timed steps each with their own roofline, cpu_baseline and parity_linf)")
+    ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of each `workloads` entry (2 warm-up steps)")
     args = ap.parse_args()
-    wl = dict(WORKLOADS[args.workload])
-    for key in ("nodes", "knn", "graphs_per_gpu"):
-        if getattr(args, key) is not None:
-            wl[key] = getattr(args, key)
-    args.nodes, args.knn, args.graphs_per_gpu = wl["nodes"], wl["knn"], wl["graphs_per_gpu"]
-    gaussian, mis = wl["diffusion"] == "gaussian", wl["task"] == "mis"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -247,6 +246,39 @@ def main():
     for kv in args.debug_set:
         k_, v_ = kv.split("=")
         _lib.check(_lib.lib().difusco_debug_set(int(k_), int(v_)))
+    out = measure(args, args.workload, args.steps, args.warmup, args.cpu_steps, not args.no_exact_fp32, rank, world, device, dry,
+                  step_flags, dist, overrides=True)
+    if rank == 0:
+        # the other sizes north_star names, on the same GPU in the same run: a few timed steps each, their own roofline
+        # (live HIP events), one oracle step on one graph with the parity of that step.  Headline fields stay TSP-1000.
+        if world == 1 and not dry and not args.no_workloads and args.workload == "tsp1000" and args.streams == 1:
+            out["workloads"] = {}
+            for name in ("tsp500", "tsp10000", "mis"):
+                t0 = time.perf_counter()
+                sub = measure(args, name, args.sub_steps, 2, 1, False, rank, world, device, dry, step_flags, dist, overrides=False)
+                keep = {k: sub[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config") if k in sub}
+                for k in ("roofline", "cpu_baseline", "parity_linf"):
+                    if k in sub:
+                        keep[k] = sub[k]
+                keep["wall_s"] = time.perf_counter() - t0
+                out["workloads"][name] = keep
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, device, dry, step_flags, dist, overrides):
+    """One workload on this rank's GPU: `warmup` untimed + `steps` timed denoise steps between fences; returns the JSON
+    record (rank 0; other ranks return None after taking part in the fences / collectives)."""
+    from difusco_amd import _lib
+    wl = dict(WORKLOADS[workload])
+    if overrides:
+        for key in ("nodes", "knn", "graphs_per_gpu"):
+            if getattr(args, key) is not None:
+                wl[key] = getattr(args, key)
+    nodes, knn, graphs_per_gpu = wl["nodes"], wl["knn"], wl["graphs_per_gpu"]
+    gaussian, mis = wl["diffusion"] == "gaussian", wl["task"] == "mis"
     from difusco_amd.dist import engine_from_broadcast, gn_allreduce, shard_range
     from difusco_amd.engine import DenoiseEngine
     from difusco_amd.models import MISModel, TSPModel
@@ -267,7 +299,7 @@ def main():
     else:
         engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion, flags=step_flags)
     margs = dict(diffusion_type=wl["diffusion"], diffusion_schedule="linear", diffusion_steps=1000,
-                 inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=args.knn if not mis else -1,
+                 inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=knn if not mis else -1,
                  n_layers=LAYERS, hidden_dim=H, inference_trick="ddim")
     gn_reduce = gn_allreduce() if (args.gn_stats == "global" and world > 1) else None
     if dry:
@@ -288,7 +320,7 @@ def main():
                                                 reorder_nodes=not args.no_node_reorder)
 
     # this rank's shard of the global batch (weak scaling: graphs_per_gpu fixed)
-    G_total = args.graphs_per_gpu * world
+    G_total = graphs_per_gpu * world
     lo, hi = shard_range(G_total, rank, world)
     gen = torch.Generator().manual_seed(77 + rank)
     if mis:
@@ -304,9 +336,9 @@ def main():
     else:
         if dry:
             from difusco_amd.synthetic import tsp_batch
-            points, edge_index = tsp_batch(args.nodes, args.knn, range(lo, hi), device)
+            points, edge_index = tsp_batch(nodes, knn, range(lo, hi), device)
         else:
-            points, edge_index = tsp_batch_gpu(args.nodes, args.knn, range(lo, hi), device)   # k-NN graphs built on the GPU
+            points, edge_index = tsp_batch_gpu(nodes, knn, range(lo, hi), device)   # k-NN graphs built on the GPU
         N_local = points.shape[0]
         xt = torch.randn(edge_index.shape[1], generator=gen)
         xt = (xt if gaussian else (xt > 0).float()).to(device)
@@ -334,7 +366,7 @@ def main():
             eng_k = DenoiseEngine(params, device=device, blob=engine.blob, precision=args.precision, fused=not args.no_fusion,
                                   flags=step_flags)
             m_k = TSPModel(margs, engine=eng_k, seed=1234 + rank + 100 * k, reorder_nodes=not args.no_node_reorder)
-            p_k, e_k = tsp_batch_gpu(args.nodes, args.knn, range(lo + k * per, lo + (k + 1) * per), device)
+            p_k, e_k = tsp_batch_gpu(nodes, knn, range(lo + k * per, lo + (k + 1) * per), device)
             x_k = torch.randn(e_k.shape[1], generator=gen)
             x_k = (x_k if gaussian else (x_k > 0).float()).to(device)
             groups.append(dict(model=m_k, points=p_k, ei=e_k, xt=x_k, stream=torch.cuda.Stream(device=device)))
@@ -361,15 +393,15 @@ def main():
         if not dry:
             torch.cuda.synchronize(device)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         xt = one_step(i, xt)
     NCAT = 5
     if not args.no_profile:
-        _lib.check(_lib.lib().difusco_profile_enable(1 if args.profile_all else 2, args.steps * (4 * LAYERS + 16)))
+        _lib.check(_lib.lib().difusco_profile_enable(1 if args.profile_all else 2, steps * (4 * LAYERS + 16)))
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        xt = one_step(args.warmup + i, xt)
+    for i in range(steps):
+        xt = one_step(warmup + i, xt)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -386,20 +418,20 @@ def main():
         prof = {"ms": list(ms), "launches": list(cnt)}
 
     if rank == 0:
-        value = G_total * args.steps / dt
+        value = G_total * steps / dt
         out = {
             "metric": ("PLUMBING DRY RUN, NO KERNEL RAN - " if dry else "") + "denoising steps/sec (graphs x steps / s), " + (
                 "MIS ER-[700,800] sparse categorical" if mis else
-                f"TSP-{args.nodes} k-NN sparse {wl['diffusion']}"),
-            "value": value, "unit": "graph-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+                f"TSP-{nodes} k-NN sparse {wl['diffusion']}"),
+            "value": value, "unit": "graph-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", **({"dry_run": True} if dry else {}),
             "config": {"workload": (f"MIS Erdos-Renyi n~U[700,800] p=0.15 (+reverse edges, +self loops) sparse categorical"
-                                    if mis else f"TSP-{args.nodes} k-NN K={args.knn} sparse {wl['diffusion']}") +
-                                   f", cosine 50-step schedule, {args.graphs_per_gpu} graphs per GPU "
+                                    if mis else f"TSP-{nodes} k-NN K={knn} sparse {wl['diffusion']}") +
+                                   f", cosine 50-step schedule, {graphs_per_gpu} graphs per GPU "
                                    f"(global batch {G_total}), H={H}, {LAYERS} layers",
-                       "name": args.workload, "graphs_per_gpu": args.graphs_per_gpu, "global_batch": G_total,
-                       "nodes": args.nodes, "knn": args.knn, "nodes_rank0": N_local, "edges_rank0": E_local,
+                       "name": workload, "graphs_per_gpu": graphs_per_gpu, "global_batch": G_total,
+                       "nodes": nodes, "knn": knn, "nodes_rank0": N_local, "edges_rank0": E_local,
                        "gn_stats": args.gn_stats,
                        "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision,
                        "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3"),
@@ -439,7 +471,7 @@ def main():
                 out["roofline"] = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": None}
             variant = ("fused" if fused else "unfused") + "-" + args.precision
-            out["roofline"]["traffic"] = pmc_traffic_bytes(kname, args.workload, E_local, variant)
+            out["roofline"]["traffic"] = pmc_traffic_bytes(kname, workload, E_local, variant)
             # "achieved" / "frac" count the matrix work ISSUED (every fp32 product is carried by n_prod 16-bit MFMA
             # products); frac_algorithmic counts each algorithmic flop once against the same peak, and
             # frac_fp32_mfma_peak against the exact-fp32 MFMA peak (what the arithmetic would cost unsplit)
@@ -451,7 +483,7 @@ def main():
                                     "frac_algorithmic": flops / avg_s / 1e12 / mfma_peak,
                                     "frac_fp32_mfma_peak": flops / avg_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                     "hbm_GBs_algorithmic": hbm_gbs, "hbm_frac_of_8TBs": hbm_gbs / PEAK_HBM_GBS,
-                                    "other_ms_per_step": 1e3 * dt / args.steps - avg_s * 1e3 * n_lin / args.steps})
+                                    "other_ms_per_step": 1e3 * dt / steps - avg_s * 1e3 * n_lin / steps})
             n_g = max(prof["launches"][2], 1)
             g_s = prof["ms"][2] / n_g * 1e-3
             if fused:
@@ -477,16 +509,16 @@ def main():
             out["kernels"].update({
                 "head": {"ms_total": prof["ms"][3], "launches": prof["launches"][3]},
                 "embed_misc": {"ms_total": prof["ms"][4], "launches": prof["launches"][4]},
-                "sum_ms_per_step": sum(prof["ms"]) / args.steps,
+                "sum_ms_per_step": sum(prof["ms"]) / steps,
             })
-        if world == 1 and not args.no_exact_fp32 and args.precision != "fp32":
+        if world == 1 and exact_fp32 and args.precision != "fp32":
             # the same workload with every E-row contraction on v_mfma_f32_32x32x2_f32 (exact fp32, no split planes):
             # the number to read when the split-precision arithmetic of the headline is not accepted
             eng32 = DenoiseEngine(params, device=device, blob=engine.blob, precision="fp32", fused=False)
             m32 = (MISModel if mis else TSPModel)(margs, engine=eng32, seed=1234, reorder_nodes=not args.no_node_reorder)
             x32 = one_step(0, xt, m32)
             fence()
-            n32 = max(2, min(4, args.steps))
+            n32 = max(2, min(4, steps))
             t0 = time.perf_counter()
             for i in range(n32):
                 x32 = one_step(1 + i, x32, m32)
@@ -496,14 +528,12 @@ def main():
             out["exact_fp32"] = {"value": G_total * n32 / d32, "unit": "graph-steps/s", "ms_per_step": 1e3 * d32 / n32,
                                  "steps": n32, "edge_linear_arithmetic": "fp32 (v_mfma_f32_32x32x2_f32), unfused kernel sequence",
                                  "same_workload": True}
-        if world == 1 and args.cpu_steps > 0:
-            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_steps, params, model, device)
+        if world == 1 and cpu_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(wl, cpu_steps, params, model, device, warm=overrides or workload != "tsp10000")
             if "parity_linf" in out["cpu_baseline"]:
                 out["parity_linf"] = out["cpu_baseline"]["parity_linf"]
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

@@ -99,6 +99,11 @@ def lib():
     L.difusco_knn_graph.argtypes = [i32, i32, vp, i64, vp, vp, vp, ctypes.c_size_t, vp]
     L.difusco_mis_decode_workspace_bytes.argtypes = [i32, ctypes.POINTER(ctypes.c_size_t)]
     L.difusco_mis_decode.argtypes = [i32, vp, vp, f32p, vp, vp, ctypes.c_size_t, ctypes.POINTER(i32), vp]
+    L.difusco_host_rowsum_f32.argtypes = [f32p, i32, ctypes.POINTER(ctypes.c_float)]
+    L.difusco_mcts_heatmap_workspace_bytes.argtypes = [i32, i64, ctypes.POINTER(ctypes.c_size_t)]
+    L.difusco_mcts_heatmap_prepare.argtypes = [i32, i64, vp, vp, f32p, f32p, ctypes.c_double, vp, ctypes.c_size_t,
+                                               ctypes.POINTER(ctypes.c_float), vp]
+    L.difusco_mcts_heatmap_rows.argtypes = [i32, i64, f32p, vp, ctypes.c_size_t, i32, i32, f32p, vp]
     if L.difusco_abi_version() != ABI_VERSION:
         raise DifuscoHipError(f"ABI version mismatch: library {L.difusco_abi_version()} != binding {ABI_VERSION}")
     _lib = L

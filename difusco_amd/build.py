@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdifusco_hip.so")
 PROF_LIB_PATH = os.path.join(LIB_DIR, "libdifusco_hip_prof.so")
-SOURCES = ["linear.hip", "linear_split.hip", "edge_layer.hip", "edge_layer_bf16.hip", "graph_kernels.hip", "decode.hip", "two_opt.hip", "knn.hip", "mis_decode.hip", "api.hip"]
+SOURCES = ["linear.hip", "linear_split.hip", "edge_layer.hip", "edge_layer_bf16.hip", "graph_kernels.hip", "decode.hip", "two_opt.hip", "knn.hip", "mis_decode.hip", "formats.hip", "api.hip"]
 PROF_SOURCES = SOURCES + ["edge_layer_abl.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "edge_layer_common.h"), os.path.join(CSRC, "edge_layer_kernel.h"),
            os.path.join(os.path.dirname(PKG), "include", "difusco_hip.h")]
@@ -32,6 +32,9 @@ EXTRA_FLAGS = {}
 if _FUSED_SCHED != "default":
     for _src in ("edge_layer.hip", "edge_layer_bf16.hip", "edge_layer_abl.hip"):
         EXTRA_FLAGS[_src] = ["-mllvm", "-amdgpu-sched-strategy=" + _FUSED_SCHED]
+
+# formats.hip reproduces a numpy float32 program bit for bit: IEEE divide / square root, no multiply-add contraction
+EXTRA_FLAGS["formats.hip"] = ["-fhip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=off"]
 
 TORCH_LIB_PATH = os.path.join(LIB_DIR, "libdifusco_torch.so")
 TORCH_SRC = os.path.join(CSRC, "torch_ops.cpp")

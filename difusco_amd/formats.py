@@ -29,8 +29,16 @@ own numpy expression, and three sweeps over the block rows do everything:
 
 Memory: O(E + block_rows * N) (about 2 M entries per buffer by default).
 
+Two implementations of the numeric part, the same numbers bit for bit:
+
+* ``mcts_heatmap_rows_gpu`` (default of ``write_mcts_heatmap`` whenever a GPU is present and the inputs are float32 - what the
+  models produce): ``csrc/formats.hip`` through the C ABI (``difusco_mcts_heatmap_prepare / _rows``); the E entries never leave
+  the device, the rows come back one block at a time for formatting.  N = 10^4: ~0.1 s instead of ~30 s.
+* ``mcts_heatmap_rows`` (host numpy; float64 inputs, hosts without a GPU): the block-row sweeps described above.
+
 The output is identical, character for character, to the reference converter's on the committed fixtures
-(``tests/golden/mcts_text_*.npz``, produced by importing ``tsp_mcts/convert_numpy_to_txt.py``)."""
+(``tests/golden/mcts_text_n30.npz``, ``mcts_text_n64.npz``, ``mcts_sparse_text_n1000_k50.npz``, produced by importing
+``tsp_mcts/convert_numpy_to_txt.py``)."""
 import os
 from typing import Iterator, Optional, Tuple
 
@@ -123,13 +131,15 @@ def _threshold_and_top3(sp: _SparseHeat, pts, k: int, block_rows: int, dtype):
         for lo, hi, v in blocks():
             top3[lo:hi] = np.argsort(v, axis=1)[:, -3:]
             parts.append(v[v > 0.0])
-        return np.sort(np.concatenate(parts))[-k], top3
+        return np.sort(np.concatenate(parts))[-k], top3       # (k = 0: index -0 = the smallest value, like the reference)
     hist = np.zeros(1 << 16, dtype=np.int64)
     for lo, hi, v in blocks():
         top3[lo:hi] = np.argsort(v, axis=1)[:, -3:]
         hist += np.bincount(v[v > 0.0].view(np.uint32) >> 16, minlength=1 << 16)
     if k > hist.sum():
         raise IndexError("fewer positive entries than expected_valid_value_num")     # the reference fails here as well
+    if k == 0:                                    # valid_values[-0] is valid_values[0]: the SMALLEST positive value
+        k = int(hist.sum())
     above = np.cumsum(hist[::-1])[::-1]                                   # positive entries in buckets >= b
     bucket = int(np.nonzero(above >= k)[0].max())
     rank = k - (int(above[bucket + 1]) if bucket + 1 < (1 << 16) else 0)  # T is the rank-th largest inside the bucket
@@ -154,8 +164,6 @@ def mcts_heatmap_rows(heat, edge_index, points, num_nodes: int, expected_valid_p
     sp = _SparseHeat(heat.astype(dtype, copy=False), edge_index, n)
     spt = _SparseHeat(sp.heat, np.stack([sp.col, sp.row]), n)               # the transposed entries: heat[j][i] at (i, j)
     k = int(n * n * expected_valid_prob)                                    # convert_numpy_to_txt.py:26
-    if k < 1:
-        raise IndexError("expected_valid_value_num is 0 (the reference would take valid_values[-0])")
     thr, top3 = _threshold_and_top3(sp, pts, k, block_rows, dtype)
     t3_rows = np.repeat(np.arange(n, dtype=np.int64), 3)
     t3_cols = top3.reshape(-1)
@@ -181,6 +189,56 @@ def mcts_heatmap_rows(heat, edge_index, points, num_nodes: int, expected_valid_p
         out = out / out.sum(axis=1, keepdims=True)                          # :47, numpy's own row sum
         for r in range(hi - lo):
             yield out[r]
+
+
+def mcts_heatmap_rows_gpu(heat, edge_index, points, num_nodes: int, expected_valid_prob: float = 0.02,
+                          block_rows: Optional[int] = None, device=None) -> Iterator[np.ndarray]:
+    """The same rows as ``mcts_heatmap_rows``, computed on the GPU (csrc/formats.hip; float32 only).  ``heat`` [E],
+    ``edge_index`` [2,E], ``points`` [N,2]: torch tensors (any device) or numpy arrays.  Yields float32 numpy rows."""
+    import ctypes
+    import torch
+    from . import _lib
+    n = int(num_nodes)
+    if device is not None:
+        dev = torch.device(device)
+    elif isinstance(heat, torch.Tensor) and heat.is_cuda:
+        dev = heat.device
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if dev.type != "cuda":
+        raise _lib.DifuscoHipError("mcts_heatmap_rows_gpu needs a GPU device")
+    as_t = lambda x, dt: torch.as_tensor(np.asarray(x) if not hasattr(x, "detach") else x).to(dev, dtype=dt).contiguous()
+    heat_d = as_t(heat, torch.float32).reshape(-1)
+    ei = as_t(edge_index, torch.int32)
+    row_d, col_d = ei[0].contiguous(), ei[1].contiguous()
+    pts_d = as_t(points, torch.float32).reshape(n, 2).contiguous()
+    E = int(heat_d.numel())
+    L = _lib.lib()
+    nbytes = ctypes.c_size_t()
+    _lib.check(L.difusco_mcts_heatmap_workspace_bytes(n, E, ctypes.byref(nbytes)))
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        thr = ctypes.c_float()
+        rc = L.difusco_mcts_heatmap_prepare(n, E, P(row_d), P(col_d), P(heat_d), P(pts_d), float(expected_valid_prob), P(ws),
+                                            ws.numel(), ctypes.byref(thr), st)
+        if rc < 0:
+            msg = L.difusco_last_error().decode()
+            if "IndexError" in msg:
+                raise IndexError(msg)
+            if "duplicate" in msg:
+                raise ValueError(msg)
+            _lib.check(rc)
+        if block_rows is None:
+            block_rows = max(1, min(n, (1 << 23) // max(n, 1)))             # ~8 M entries (32 MB) per device block
+        out = torch.empty((min(block_rows, n), n), dtype=torch.float32, device=dev)
+        for lo in range(0, n, block_rows):
+            cnt = min(block_rows, n - lo)
+            _lib.check(L.difusco_mcts_heatmap_rows(n, E, P(pts_d), P(ws), ws.numel(), lo, cnt, P(out), st))
+            host = out[:cnt].cpu().numpy()
+            for r in range(cnt):
+                yield host[r]
 
 
 def _format_rows(rows: Iterator[np.ndarray], n: int) -> Iterator[bytes]:
@@ -216,22 +274,48 @@ def mcts_heatmap_text(adj_matrix: np.ndarray, points: np.ndarray, num_nodes: int
     return f"{num_nodes}\n" + b"".join(_format_rows(rows, num_nodes)).decode()
 
 
-def write_mcts_heatmap(heat, points, num_nodes: int, output_dir: str, index: int, heatmap_prefix: str = "heatmap",
-                       expected_valid_prob: float = 0.02, edge_index=None, block_rows: int = 256) -> str:
-    """File name and directory layout of convert_numpy_to_txt.py:60-66; rows are streamed to the file.  ``heat`` is
-    either a dense [N,N] array (``edge_index`` None) or the sparse [E] heatmap on ``edge_index`` [2,E] - numpy arrays or
-    torch tensors (the sampler's output is moved to the host: E floats)."""
+def _gpu_available() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def write_mcts_heatmap(heat=None, points=None, num_nodes: int = None, output_dir: str = None, index: int = 0,
+                       heatmap_prefix: str = "heatmap", expected_valid_prob: float = 0.02, edge_index=None,
+                       block_rows: Optional[int] = None, use_gpu: Optional[bool] = None, adj_matrix=None) -> str:
+    """File name and directory layout of convert_numpy_to_txt.py:60-66; rows are streamed to the file.  ``heat`` (alias
+    ``adj_matrix``, the reference's name for the dense input) is either a dense [N,N] array (``edge_index`` None) or the
+    sparse [E] heatmap on ``edge_index`` [2,E] - numpy arrays or torch tensors.  ``use_gpu``: None = the GPU kernels when a
+    GPU is present and the values are float32 (csrc/formats.hip), the host numpy sweeps otherwise; both give the same text."""
+    if heat is None:
+        heat = adj_matrix
+    if heat is None or points is None or num_nodes is None or output_dir is None:
+        raise TypeError("write_mcts_heatmap needs heat (or adj_matrix), points, num_nodes and output_dir")
+
     def host(x):
         return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
-    heat, points = host(heat), host(points)
-    if edge_index is None:
-        heat, edge_index = sparsify(heat)
-    else:
-        edge_index = host(edge_index)
+
+    def is_f32(x):
+        return str(getattr(x, "dtype", "")).replace("torch.", "") == "float32"
+    if use_gpu is None:
+        use_gpu = _gpu_available() and is_f32(heat) and is_f32(points)
     folder = f"{output_dir}/{heatmap_prefix}/tsp{num_nodes}"
     os.makedirs(folder, exist_ok=True)
     path = f"{folder}/heatmaptsp{num_nodes}_{index}.txt"
-    rows = mcts_heatmap_rows(heat, edge_index, points, num_nodes, expected_valid_prob, block_rows)
+    if use_gpu:
+        if edge_index is None:
+            dense = host(heat)
+            heat, edge_index = sparsify(dense.astype(np.float32, copy=False))
+        rows = mcts_heatmap_rows_gpu(heat, edge_index, points, num_nodes, expected_valid_prob, block_rows)
+    else:
+        heat, points = host(heat), host(points)
+        if edge_index is None:
+            heat, edge_index = sparsify(heat)
+        else:
+            edge_index = host(edge_index)
+        rows = mcts_heatmap_rows(heat, edge_index, points, num_nodes, expected_valid_prob, block_rows or 256)
     with open(path, "wb") as f:
         f.write(f"{num_nodes}\n".encode())
         for line in _format_rows(rows, num_nodes):

@@ -292,6 +292,26 @@ int difusco_tsp_two_opt_workspace_bytes(int n_nodes, int batch, size_t* bytes);
 int difusco_tsp_two_opt(int n_nodes, int batch, const double* points, int32_t* tours, int64_t max_iterations,
                         void* workspace, size_t workspace_bytes, int64_t* iterations_out, void* stream);
 
+/* ---- MCTS heatmap rows: the numeric part of tsp_mcts/convert_numpy_to_txt.py:18-47, whose text output
+ * (first line N, then N rows of N "%.6f" numbers) tsp_mcts/code/include/TSP_IO.h:461-492 reads.  From the SPARSE heatmap:
+ * row/col/heat [n_edges] DEVICE, any order, no duplicate (row, col); points DEVICE float32 [n_nodes,2]; float32 arithmetic
+ * in numpy's operation order (no fused multiply-add, numpy's chunked pairwise row sums), so that the rows equal the
+ * reference program's bit for bit.  prepare(): CSR of heat and its transpose, the threshold (k-th largest positive value,
+ * k = int(N*N*prob), exact radix select; k = 0 selects the smallest positive value like the reference's
+ * valid_values[-0]) and the row top-3 - kept in `workspace`; *threshold_out (HOST, optional).  rows(): the normalised
+ * rows [row_begin, row_begin + row_count) into out_rows (DEVICE, [row_count, n_nodes]).  n_nodes <= 38000 (a row lives
+ * in LDS).  Both block until done. */
+/* HOST helper (no GPU): the float32 sum of a[0..n) in the order of the row-sum program the kernels execute (numpy's
+ * add.reduce over a contiguous float32 row: 8192-element chunks, pairwise summation inside) - exported so that the CPU
+ * tests can hold that program against numpy itself. */
+int difusco_host_rowsum_f32(const float* a, int n, float* out);
+int difusco_mcts_heatmap_workspace_bytes(int n_nodes, int64_t n_edges, size_t* bytes);
+int difusco_mcts_heatmap_prepare(int n_nodes, int64_t n_edges, const int32_t* row, const int32_t* col, const float* heat,
+                                 const float* points, double expected_valid_prob, void* workspace, size_t workspace_bytes,
+                                 float* threshold_out, void* stream);
+int difusco_mcts_heatmap_rows(int n_nodes, int64_t n_edges, const float* points, const void* workspace,
+                              size_t workspace_bytes, int row_begin, int row_count, float* out_rows, void* stream);
+
 /* ---- in-library profiler (bench.py): HIP events on the launch stream around every kernel launch of
  * difusco_denoise_step, summed per category.  Categories: 0 edge-row linear (rows = n_edges),
  * 1 node-row linear, 2 edge gate/aggregate, 3 head (GroupNorm+conv+posterior, 3 launches),

@@ -376,3 +376,123 @@ def test_solve_mis_pipeline(dev):
     covered = np.zeros(n, dtype=bool)
     covered[a[sol[b] == 1]] = True
     assert np.all(covered | (sol == 1))
+
+
+# ------------------------------------------------------------------------------------------------
+# (f)-4 on the GPU: the MCTS heatmap text (tsp_mcts/convert_numpy_to_txt.py:18-72) from csrc/formats.hip
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["mcts_text_n30", "mcts_text_n64", "mcts_sparse_text_n1000_k50"])
+def test_mcts_text_gpu_is_character_identical_to_the_reference(dev, golden_dir, tmp_path, name):  # noqa: F811
+    """The GPU rows, formatted, equal the text the reference converter wrote (fixtures produced by importing
+    tsp_mcts/convert_numpy_to_txt.py): every one of the N^2 "%.6f" numbers, the signed zeros included."""
+    from difusco_amd import formats
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    n, prob = int(z["num_nodes"]), float(z["expected_valid_prob"])
+    ref_text = bytes(z["text"]).decode()
+    ei = z["edge_index"] if "edge_index" in z.files else None
+    path = formats.write_mcts_heatmap(torch.from_numpy(z["heat"]).to(dev), torch.from_numpy(z["points"]).to(dev), n, str(tmp_path), 0,
+                                      expected_valid_prob=prob, edge_index=None if ei is None else torch.from_numpy(ei).to(dev),
+                                      use_gpu=True)
+    assert open(path).read() == ref_text
+    if ei is not None:          # block size and entry order do not matter; rows equal the host numpy sweeps bit for bit
+        host = np.stack(list(formats.mcts_heatmap_rows(z["heat"], ei, z["points"], n, prob)))
+        perm = np.random.default_rng(0).permutation(z["heat"].shape[0])
+        for br, hh, ee in [(37, z["heat"], ei), (1000, z["heat"][perm], ei[:, perm])]:
+            got = np.stack(list(formats.mcts_heatmap_rows_gpu(hh, ee, z["points"], n, prob, block_rows=br, device=dev)))
+            assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), host.view(np.uint32))
+
+
+def test_mcts_rows_gpu_equal_host_numpy_and_edge_cases(dev):
+    """A k-NN heatmap at N = 3000 (9 M values, threshold among prior-only entries): GPU rows == the host numpy sweeps bit
+    for bit; k = 0 (the reference's valid_values[-0]), too few positive values (IndexError upstream), duplicate entries."""
+    from difusco_amd import formats
+    from difusco_amd.synthetic import tsp_instance
+    n, K = 3000, 40
+    pts, ei = tsp_instance(n, K, seed=5)
+    rng = np.random.default_rng(6)
+    heat = (rng.random(ei.shape[1]) ** 3).astype(np.float32)
+    heat[rng.random(ei.shape[1]) < 0.3] = 0.0
+    host = np.stack(list(formats.mcts_heatmap_rows(heat, ei, pts.astype(np.float32), n, 0.02)))
+    got = np.stack(list(formats.mcts_heatmap_rows_gpu(heat, ei, pts.astype(np.float32), n, 0.02, device=dev)))
+    assert np.array_equal(got.view(np.uint32), host.view(np.uint32))
+    # small instance: k = 0 and an unreachable k
+    n2 = 12
+    p2 = rng.random((n2, 2)).astype(np.float32)
+    h2, e2 = formats.sparsify((rng.random((n2, n2)) ** 2).astype(np.float32))
+    a = np.stack(list(formats.mcts_heatmap_rows(h2, e2, p2, n2, 0.001)))          # int(144 * 0.001) = 0
+    b = np.stack(list(formats.mcts_heatmap_rows_gpu(h2, e2, p2, n2, 0.001, device=dev)))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    far = (p2 * 50).astype(np.float32)                                            # distances > 1: negative priors
+    with pytest.raises(IndexError):
+        list(formats.mcts_heatmap_rows_gpu(np.zeros(1, np.float32), np.array([[0], [1]]), far, n2, 0.9, device=dev))
+    with pytest.raises(ValueError):
+        list(formats.mcts_heatmap_rows_gpu(np.ones(2, np.float32), np.array([[0, 0], [1, 1]]), p2, n2, 0.5, device=dev))
+
+
+def test_mcts_rows_gpu_full_size(dev):
+    """N = 10^4, K = 100 (the TSP-10000 heatmap): the numeric part in well under a second (31 s of host numpy in round 2);
+    the threshold is the k-th largest of the 10^8 values (counted independently with torch), rows are normalised, the
+    support is symmetric, and a sample of rows equals the converter's statements evaluated for those rows."""
+    import ctypes
+    import time
+    from difusco_amd import _lib, formats
+    from difusco_amd.synthetic import tsp_batch_gpu
+    n, K, prob = 10000, 100, 0.02
+    pts, ei = tsp_batch_gpu(n, K, range(1), dev)
+    g = torch.Generator().manual_seed(8)
+    heat = (torch.rand(ei.shape[1], generator=g) ** 4).to(dev)
+    row, col = ei[0].int().contiguous(), ei[1].int().contiguous()
+    pts = pts.float().contiguous()
+    L = _lib.lib()
+    nb = ctypes.c_size_t()
+    _lib.check(L.difusco_mcts_heatmap_workspace_bytes(n, ei.shape[1], ctypes.byref(nb)))
+    ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    out = torch.empty((n, n), dtype=torch.float32, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    thr = ctypes.c_float()
+    best = 1e9
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _lib.check(L.difusco_mcts_heatmap_prepare(n, ei.shape[1], P(row), P(col), P(heat), P(pts), prob, P(ws), ws.numel(),
+                                                  ctypes.byref(thr), st))
+        _lib.check(L.difusco_mcts_heatmap_rows(n, ei.shape[1], P(pts), P(ws), ws.numel(), 0, n, P(out), st))
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    print(f"MCTS heatmap rows, N={n} K={K}: {best * 1e3:.1f} ms for the numeric part (threshold {thr.value:.6g})")
+    assert best < 1.0
+    # the threshold is the k-th largest positive value: count with torch, block by block (same float32 operations)
+    k = int(n * n * prob)
+    dense_heat = torch.zeros((n, n), dtype=torch.float32, device=dev)
+    dense_heat[ei[0], ei[1]] = heat
+    gt = ge = 0
+    top3 = torch.empty((n, 3), dtype=torch.int64, device=dev)
+    for lo in range(0, n, 1000):
+        dx = pts[lo:lo + 1000, None, 0] - pts[None, :, 0]
+        dy = pts[lo:lo + 1000, None, 1] - pts[None, :, 1]
+        v = dense_heat[lo:lo + 1000] + 0.01 * (1.0 - torch.sqrt(dx * dx + dy * dy))
+        gt += int((v > thr.value).sum())
+        ge += int((v >= thr.value).sum())
+        top3[lo:lo + 1000] = v.topk(3, dim=1).indices
+    assert gt < k <= ge, (gt, k, ge)
+    sums = out.sum(dim=1)
+    assert (sums - 1).abs().max().item() < 1e-4 and torch.isfinite(out).all()
+    nz = out != 0
+    assert torch.equal(nz, nz.t())
+    # rows 3000..3007 against the converter's statements evaluated for those rows on the host (numpy, float32)
+    ph, hh, t3 = pts.cpu().numpy(), dense_heat.cpu().numpy(), top3.cpu().numpy()
+    rows = np.arange(3000, 3008)
+    d = np.linalg.norm(ph[rows][:, None, :] - ph[None, :, :], axis=-1)                  # [8, n]
+    v_r = hh[rows] + 0.01 * (1.0 - d)                                                   # v[i][j]
+    v_c = hh[:, rows].T + 0.01 * (1.0 - np.linalg.norm(ph[None, :, :] - ph[rows][:, None, :], axis=-1))   # v[j][i] at [i][j]
+    keep_r = v_r > thr.value
+    keep_r[np.arange(8)[:, None], t3[rows]] = True
+    keep_c = v_c > thr.value
+    keep_c |= (t3[None, :, :] == rows[:, None, None]).any(axis=2)                      # i among the top 3 of row j
+    m_r, m_c = v_r * keep_r, v_c * keep_c
+    m_r[m_r != 0.0] += np.float32(1e-2)
+    m_c[m_c != 0.0] += np.float32(1e-2)
+    want = m_r + m_c
+    want = want / want.sum(axis=1, keepdims=True)
+    assert np.array_equal(out[3000:3008].cpu().numpy().view(np.uint32), want.astype(np.float32).view(np.uint32))

@@ -535,3 +535,44 @@ def test_mcts_text_from_sparse_heatmap_matches_reference(golden_dir, tmp_path):
     assert open(path2).read() == ref_text
     with pytest.raises(ValueError):
         list(formats.mcts_heatmap_rows(np.ones(2, np.float32), np.array([[0, 0], [1, 1]]), z["points"][:4], 4, 0.5))
+
+
+def test_row_sum_program_is_numpys_own_order():
+    """csrc/formats.hip sums an output row of the MCTS heatmap in the order numpy's float32 add.reduce uses (8192-element
+    ufunc-buffer chunks, pairwise summation inside, eight interleaved accumulators per <=128-element block): the host twin of
+    that program against np.sum itself, on lengths around every boundary of the scheme."""
+    rng = np.random.default_rng(5)
+    out = ctypes.c_float()
+    for n in [1, 5, 7, 8, 9, 63, 128, 129, 130, 255, 256, 257, 1000, 1001, 4099, 8191, 8192, 8193, 8200, 10000, 16384, 20011, 38000]:
+        for trial in range(3):
+            a = (rng.random(n) ** 3 * 10.0 ** rng.integers(-3, 3)).astype(np.float32)
+            if trial == 2:
+                a[rng.random(n) < 0.9] = 0.0                                   # mostly zeros, like a thresholded row
+            _lib.check(_lib.lib().difusco_host_rowsum_f32(a.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(out)))
+            want = a.reshape(1, n).sum(axis=1, keepdims=True)[0, 0]
+            assert np.float32(out.value) == want, (n, trial, out.value, want)
+
+
+def test_mcts_k_zero_selects_the_smallest_positive_value():
+    """int(N*N*prob) == 0 -> the reference's valid_values[-0] is valid_values[0], the SMALLEST positive value
+    (every other positive entry is kept); the product used to raise instead."""
+    from difusco_amd import formats
+    rng = np.random.default_rng(3)
+    n = 6
+    pts = rng.random((n, 2)).astype(np.float32)
+    heat = (rng.random((n, n)) ** 2).astype(np.float32)
+    rows = np.stack(list(formats.mcts_heatmap_rows(*formats.sparsify(heat), pts, n, expected_valid_prob=0.01)))     # int(36*0.01) = 0
+    # the reference's statements on the dense matrix
+    d = np.linalg.norm(pts[:, None, :] - pts[None, :, :], axis=-1)
+    adj = heat + 0.01 * (1.0 - d)
+    vals = np.sort(adj[adj > 0.0])
+    thr = vals[-0]
+    assert thr == vals[0]
+    top3 = np.argsort(adj, axis=1)[:, -3:]
+    mask = adj > thr
+    mask[np.arange(n)[:, None], top3] = True
+    adj = adj * mask
+    adj[adj != 0.0] += 1e-2
+    adj = adj + adj.T
+    adj = adj / adj.sum(axis=1, keepdims=True)
+    assert np.array_equal(rows, adj)
