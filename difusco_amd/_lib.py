@@ -66,6 +66,7 @@ def lib():
     # DIFUSCO_PROFILING_LIB=1 loads the profiling build (libdifusco_hip_prof.so: the same code plus the timing-only
     # kernel variants and their process-wide knobs, `python -m difusco_amd.build --prof`); never set in production
     path = PROF_LIB_PATH if os.environ.get("DIFUSCO_PROFILING_LIB", "0") not in ("", "0") else LIB_PATH
+    path = os.environ.get("DIFUSCO_HIP_LIBRARY", path)      # A/B of two builds of the same ABI (benchmarking only)
     if not os.path.exists(path):
         raise DifuscoHipError(
             f"{path} is missing: build it with `python -m difusco_amd.build` "
@@ -104,6 +105,14 @@ def lib():
     L.difusco_mcts_heatmap_prepare.argtypes = [i32, i64, vp, vp, f32p, f32p, ctypes.c_double, vp, ctypes.c_size_t,
                                                ctypes.POINTER(ctypes.c_float), vp]
     L.difusco_mcts_heatmap_rows.argtypes = [i32, i64, f32p, vp, ctypes.c_size_t, i32, i32, f32p, vp]
+    if path == PROF_LIB_PATH:
+        # profiling library only: DIFUSCO_DEBUG_SET="key=value,key=value" applies difusco_debug_set at load time, so that
+        # whole test runs / benches can be pointed at an A/B kernel variant (e.g. "7=8051")
+        L.difusco_debug_set.argtypes = [i32, i32]
+        for kv in filter(None, os.environ.get("DIFUSCO_DEBUG_SET", "").split(",")):
+            k_, v_ = kv.split("=")
+            if L.difusco_debug_set(int(k_), int(v_)) < 0:
+                raise DifuscoHipError(f"difusco_debug_set({kv}) failed: {L.difusco_last_error().decode()}")
     if L.difusco_abi_version() != ABI_VERSION:
         raise DifuscoHipError(f"ABI version mismatch: library {L.difusco_abi_version()} != binding {ABI_VERSION}")
     _lib = L

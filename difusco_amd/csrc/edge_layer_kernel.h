@@ -148,6 +148,24 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
   }
+  // OPT bit 12: PERSISTENT workgroups.  The grid is 2 workgroups per CU (the residency the 78 KB of LDS allow); workgroup
+  // (XCD x = blockIdx % 8, position idx) walks the 128-edge groups start_x + idx, + q, + 2q, ... of the contiguous range of
+  // its XCD (the same locality as bit 0).  The layer parameters are written to LDS once, the weight-stage ring simply
+  // continues into the next group (its first stage is requested during the last stage of the current one), and the first
+  // e slabs / the tile scale of the next group are requested before the last output phase: the per-tile prologue (5.5 k
+  // of 122 k cycles: first-stage and e latency, parameter fill) disappears.  A launch with no more groups than workgroups
+  // runs every workgroup once, exactly like the non-persistent kernel.
+  constexpr bool kPersist = (OPT & 4096) != 0;
+  const int n_wgt = (n_edges + 32 * WAVES - 1) / (32 * WAVES);
+  int wt = bid, wt_end = bid + 1, wt_step = 1;
+  if (kPersist && (int)gridDim.x < n_wgt) {
+    const int q = (int)gridDim.x >> 3, x = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;      // (grid: a multiple of 8)
+    const int base = n_wgt >> 3, rem = n_wgt & 7;
+    const int start = x * base + (x < rem ? x : rem);
+    wt = start + idx;
+    wt_end = start + base + (x < rem ? 1 : 0);
+    wt_step = q;
+  }
   // start_delay > 0 (experiment, profiling library): the workgroups that take the SECOND slot of every CU in the first
   // dispatch generation (positions 32..63 of their XCD) start that many cycles late, so that the two resident workgroups of
   // a CU begin out of phase (one in its matrix phases while the other is in its VALU phases); later generations inherit
@@ -159,16 +177,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)start_delay) __builtin_amdgcn_s_sleep(32);
     }
   }
-  const int tile = bid * WAVES + wave;
-  const int s_raw = tile * 32 + l31;
-  const bool valid = s_raw < n_edges;
-  const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
-  // e is stored TILED ("MFMA native", see edge_tiled_offset in kernels.h): per 32-edge tile the 1 KiB that one
-  // wave instruction touches is contiguous, so every access below is a fully coalesced 1 KiB transaction
-  // Addressing is (wave-uniform 64-bit base + compile-time constant) + 32-bit lane offset so that the loads use
-  // the scalar-base form; per-lane 64-bit pointers with large constant offsets cost a VGPR pair per address.
-  float* const etile = e + (long long)tile * (32 * H);   // + slab * 512 + i * 256 + loff
   const unsigned loff = lane * 4;
+  const int loff_b = lane * 16;
+  float* scr = scr_all + wave * 32 * SCR_STRIDE;
+  typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
   // OPT bit 4: the e stream (read once, written once per layer: 1.6 GB per launch) moves with non-temporal accesses, so
   // that it does not push the neighbour-table rows and the weight planes - both re-read by every workgroup of the
   // XCD - out of the 4 MiB L2
@@ -180,66 +192,39 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // as well measured the same, and buffer_store_dwordx4 with an SGPR soffset needs a hand-placed wait state on gfx950
   // (profiles/r02/fused_kernel_study.txt, "buffer stores").
   constexpr bool kBufRing = (OPT & 256) != 0;
-  typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(etile, 0, 32 * H * 4, 0x00020000);
-  const int loff_b = lane * 16;
   // OPT bit 10: the GEMM 1 slabs are read with the default cache policy; the residual re-read (last use) and the stores stay
   // non-temporal.  Measured on one box, graph-steps/s: all three non-temporal 785.1 | slabs default 802.6 | residual default
   // 765.4 | slabs + residual default 782.5 | stores default 759.4 | slabs + stores default 774.9.
   constexpr bool kNtRing = kNt && (OPT & 1024) == 0, kNtRes = kNt, kNtSt = kNt;
-  auto ld_e = [&](int off, bool buf = false) -> v4f {       // off: float offset inside the tile (a constant at every call)
-    if (buf) {
-      const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rs_e, loff_b, off * 4, kNtRing ? 2 : 0);
-      return __builtin_bit_cast(v4f, r);
-    } else {
-      const float* p = etile + off + loff;
-      if constexpr (kNtRes) return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
-      else return *reinterpret_cast<const v4f*>(p);
-    }
-  };
-  auto st_e = [&](int off, v4f v) {
-    float* p = etile + off + loff;
-    if constexpr (kNtSt) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
-    else *reinterpret_cast<v4f*>(p) = v;
-  };
-  float* scr = scr_all + wave * 32 * SCR_STRIDE;
-  float sx = 1.0f, inv1 = 1.0f, inv2 = 1.0f, sa = 1.0f, nsig = -1.4426950408889634f;
-  if constexpr (T::kScaled) {
-    inv2 = scales[1];
-    sa = scales[2];
-    nsig = scales[3];
-    if constexpr (!L0) {
-      float invx;
-      sx = pow2_scale_for(etmax_in[tile], invx);      // (tile is wave uniform: scalar load, scalar arithmetic)
-      inv1 = scales[0] * invx;
-    }
-  }
-  float tmx = 0.0f;      // max |e_new| over this lane's share of the tile (kScaled: becomes etmax_out[tile])
-  // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
-  unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define FUSED_STAMP(k) \
-  if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();
-  FUSED_STAMP(0)
-
-  // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}] = two float4 of the tiled
-  // layout = 2 KiB per wave and slab, cold HBM reads.
-  // A register ring, RING slabs ahead of the MFMAs.  (Routing this stream through LDS-DMA into the idle aggregation
-  // scratch was measured 2.5 % slower - profiles/r01/fused_kernel_study.txt - and removed.)
   // profiling only (wrong results): matrix phases without stage refills and barriers / without the e stream
   constexpr bool kNoSync = (ABL & 16384) != 0, kNoE = (ABL & 32768) != 0;
   // profiling only (races, wrong results): stage requests never waited for / no stage barrier
   constexpr bool kNoWait = (ABL & 65536) != 0, kNoBar = (ABL & 131072) != 0;
+  // B operand of GEMM 1: slab ks needs e[s][16 ks + {4hh..4hh+3, 8+4hh..8+4hh+3}] = two float4 of the tiled
+  // layout = 2 KiB per wave and slab, cold HBM reads.
+  // A register ring, RING slabs ahead of the MFMAs.  (Routing this stream through LDS-DMA into the idle aggregation
+  // scratch was measured 2.5 % slower - profiles/r01/fused_kernel_study.txt - and removed.)
   constexpr int RING = 2;
   v4f er[RING][2];
-  if constexpr (L0) {
-    // no e stream
-  } else {
+  // the first RING slabs of tile `tl` (e is TILED, see below) into the ring
+  auto ring_fill = [&](int tl) {
+    float* const et = e + (long long)tl * (32 * H);
+    if constexpr (kBufRing) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(et, 0, 32 * H * 4, 0x00020000);
 #pragma unroll
-    for (int d = 0; d < RING; ++d) {
-      er[d][0] = ld_e(d * 512, kBufRing);
-      er[d][1] = ld_e((d * 512 + 256), kBufRing);
+      for (int d = 0; d < RING; ++d) {
+        er[d][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, loff_b, d * 2048, kNtRing ? 2 : 0));
+        er[d][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, loff_b, d * 2048 + 1024, kNtRing ? 2 : 0));
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < RING; ++d) {
+        er[d][0] = *reinterpret_cast<const v4f*>(et + d * 512 + loff);
+        er[d][1] = *reinterpret_cast<const v4f*>(et + d * 512 + 256 + loff);
+      }
     }
-  }
+  };
+  float tmax_cur = 0.0f;      // max |e| of the current tile (kScaled; left by the producer of e in etmax_in)
 
   // ---- weight stage streaming ---------------------------------------------------------------------
   // A stage is ENT rows of 32 bytes per plane (16 KiB for the two planes):
@@ -252,7 +237,9 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // entry = (PP w + i) * 32 + (L >> 1), and fetches the half that belongs there (the XOR of wslot applied on the
   // source side; both halves of an entry are adjacent in global memory, so coalescing is unchanged).
   // Protocol: iteration t requests stage t+1 into the other buffer (everybody left it at the last barrier),
-  // multiplies stage t, then waits for its own requests before the barrier.
+  // multiplies stage t, then waits for its own requests before the barrier.  The last stage of a tile (LAST_T) requests
+  // the FIRST stage of the workgroup's next tile (persistent kernel; the stage count per tile is even, so the buffer
+  // parity carries over) - that request is waited for at the top of the next tile.
   unsigned dvoff1, dvoff2;
   {
     const int entry0 = (PP * wave) * 32 + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
@@ -262,6 +249,9 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c_planes), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(o_planes), 0, 0x7fffffff, 0x00020000);
   const int plane_bytes = (int)plane_stride * 2;
+  constexpr int FIRST_T = L0 ? NS1 : 0;                       // first stage of a tile (layer 0 has no GEMM 1)
+  constexpr int LAST_T = TAIL == 2 ? NS1 - 1 : NSTAGE - 1;    // last stage of a tile (MIS last layer: no GEMM 2)
+  static_assert(((LAST_T + 1 - FIRST_T) & 1) == 0, "an even number of stages per tile keeps the buffer parity");
   // piece i of this wave (i < PP): LDS slot block PP*wave + i; its source lies i * 512 elements further in a GEMM 1
   // stage ([slab][256 rows][16]) and (i >> 1) * 4096 + (i & 1) * 512 in a GEMM 2 stage ([k slab][64 rows][16]) when a
   // wave covers more than one k slab (PP = 4), i * 512 otherwise
@@ -282,25 +272,41 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   }
 #define FUSED_PIPE_BEGIN(t)                                         \
   if constexpr (!kNoSync) {                                         \
-    if ((t) + 1 < NSTAGE) {                                         \
+    if ((t) < LAST_T) {                                             \
       FUSED_DMA_STAGE((t) + 1)                                      \
+      __builtin_amdgcn_sched_barrier(0);                            \
+    } else if (has_next) {                                          \
+      FUSED_DMA_STAGE(FIRST_T)                                      \
       __builtin_amdgcn_sched_barrier(0);                            \
     }                                                               \
   }
   // end of iteration t: the requests of stage t+1 must have landed before the barrier.  In GEMM 1 with the e
   // stream on the DMA queue as well, the two youngest requests are slab t+2 of e, which may stay in flight.
 #define FUSED_PIPE_END(t)                                                        \
-  if (!kNoSync && (t) + 1 < NSTAGE) {                                            \
+  if (!kNoSync && (t) < LAST_T) {                                                \
     if constexpr (!kNoWait) {                                                    \
       __builtin_amdgcn_s_waitcnt(0x0F70);                            /* vmcnt(0) */ \
     }                                                                            \
     if constexpr (!kNoBar) __syncthreads();                                      \
   }
+#define FUSED_STAMP(k) \
+  if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();
 
-  if constexpr (L0) { FUSED_DMA_STAGE(NS1) }           // no GEMM 1: the stage stream starts with GEMM 2
-  else { FUSED_DMA_STAGE(0) }
-
-  // layer parameters -> LDS (thread = feature)
+  float inv2 = 1.0f, sa = 1.0f, nsig = -1.4426950408889634f, inv_c = 1.0f;
+  if constexpr (T::kScaled) {
+    inv_c = scales[0];
+    inv2 = scales[1];
+    sa = scales[2];
+    nsig = scales[3];
+  }
+  // ---- once per workgroup: requests of its first tile, layer parameters -> LDS (thread = feature) ------------------
+  if (wt < wt_end) {
+    if constexpr (!L0) {
+      ring_fill(wt * WAVES + wave);
+      if constexpr (T::kScaled) tmax_cur = etmax_in[wt * WAVES + wave];      // (wave uniform: scalar load)
+    }
+    FUSED_DMA_STAGE(FIRST_T)
+  }
   if (tid < H) {
     prm[P_BC * H + tid] = b_c[tid];
     prm[P_GE * H + tid] = g_e[tid];
@@ -316,19 +322,61 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       prm[P_CE1 * H + tid] = l0_table[3 * H + tid];
     }
   }
+  const int a_off = wslot(l31, hh);   // entry = 32 nb + l31 : (entry >> 3) & 1 == (l31 >> 3) & 1
+
+#pragma unroll 1
+  for (; wt < wt_end; wt += wt_step) {
+  const bool has_next = kPersist && wt + wt_step < wt_end;      // (wave uniform)
+  const int tile = wt * WAVES + wave;
+  const int s_raw = tile * 32 + l31;
+  const bool valid = s_raw < n_edges;
+  const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
+  // e is stored TILED ("MFMA native", see edge_tiled_offset in kernels.h): per 32-edge tile the 1 KiB that one
+  // wave instruction touches is contiguous, so every access below is a fully coalesced 1 KiB transaction
+  // Addressing is (wave-uniform 64-bit base + compile-time constant) + 32-bit lane offset so that the loads use
+  // the scalar-base form; per-lane 64-bit pointers with large constant offsets cost a VGPR pair per address.
+  float* const etile = e + (long long)tile * (32 * H);   // + slab * 512 + i * 256 + loff
+  const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(etile, 0, 32 * H * 4, 0x00020000);
+  auto ld_e = [&](int off, bool buf = false) -> v4f {       // off: float offset inside the tile (a constant at every call)
+    if (buf) {
+      const v4u_ r = __builtin_amdgcn_raw_buffer_load_b128(rs_e, loff_b, off * 4, kNtRing ? 2 : 0);
+      return __builtin_bit_cast(v4f, r);
+    } else {
+      const float* p = etile + off + loff;
+      if constexpr (kNtRes) return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+      else return *reinterpret_cast<const v4f*>(p);
+    }
+  };
+  auto st_e = [&](int off, v4f v) {
+    float* p = etile + off + loff;
+    if constexpr (kNtSt) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
+    else *reinterpret_cast<v4f*>(p) = v;
+  };
+  float sx = 1.0f, inv1 = 1.0f;
+  if constexpr (T::kScaled && !L0) {
+    float invx;
+    sx = pow2_scale_for(tmax_cur, invx);      // (wave uniform: scalar arithmetic)
+    inv1 = inv_c * invx;
+  }
+  float tmx = 0.0f;      // max |e_new| over this lane's share of the tile (kScaled: becomes etmax_out[tile])
+  // phase timestamps live in SGPRs and are written once at the end (ABL & 16 only)
+  unsigned long long stamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  FUSED_STAMP(0)
+
+  v16f acc1[8];
+  // top of a tile: its first weight stage (requested during the previous tile's last stage, or above), the ring slabs and
+  // - first tile - the parameters have landed
   // layer 0: this lane's table row (float offset into prm), rule of table_rows_tiled_kernel
   int l0_row = P_TAB0 * H;
   if constexpr (L0) {
     if (l0_x != nullptr && l0_x[l0_perm ? l0_perm[s] : s] > 0.5f) l0_row = P_TAB1 * H;
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  __syncthreads();
   const int j = col[s];
   const int i_node = row[s];
   const float* nj = node4 + (long long)j * 4 * H;       // rows U | V | A | B
   const float* ni = node4 + (long long)i_node * 4 * H;
-
-  v16f acc1[8];
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): stage 0 has landed
-  __syncthreads();
 
   FUSED_STAMP(1)
   if constexpr (L0) {      // C e_in of this lane's features, from the row that belongs to its input row
@@ -347,8 +395,6 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.0f;
   }
-
-  const int a_off = wslot(l31, hh);   // entry = 32 nb + l31 : (entry >> 3) & 1 == (l31 >> 3) & 1
 
   // ================================ GEMM 1 ==========================================================
   // OPT bit 5: two stages of cover for the e stream.  The slab of stage t is split BEFORE this stage's weight requests
@@ -474,7 +520,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   float* part0 = part + ((long long)tile * 2 + 0) * H;
   float* part1 = part + ((long long)tile * 2 + 1) * H;
 
-  v4f ga[2][2][3];
+  // OPT bit 13 (experiment): neighbour-table rows gathered TWO batches ahead of their use (three ring slots) instead of one
+  constexpr bool kG2 = (OPT & 8192) != 0;
+  constexpr int GD = kG2 ? 3 : 2;
+  v4f ga[GD][2][3];
 #define FUSED_GATHER(b, buf)                                                          \
   {                                                                                   \
     _Pragma("unroll") for (int q2 = 0; q2 < 2; ++q2) {                                \
@@ -493,9 +542,14 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     }                                                                                 \
   }
   FUSED_GATHER(0, 0)
+  if constexpr (kG2) { FUSED_GATHER(1, 1) }
 #pragma unroll
   for (int b = 0; b < 16; ++b) {             // batch b: block nb = b >> 1, quads g = 2 (b & 1) + {0, 1}
-    if (b + 1 < 16) {
+    if constexpr (kG2) {
+      if (b + 2 < 16) {
+        if ((b + 2) % 3 == 0) FUSED_GATHER(b + 2, 0) else if ((b + 2) % 3 == 1) FUSED_GATHER(b + 2, 1) else FUSED_GATHER(b + 2, 2)
+      }
+    } else if (b + 1 < 16) {
       if (((b + 1) & 1) == 0) FUSED_GATHER(b + 1, 0) else FUSED_GATHER(b + 1, 1)
     }
     if constexpr ((OPT & 256) != 0) __builtin_amdgcn_sched_barrier(0);
@@ -505,7 +559,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       const int g = 2 * (b & 1) + q2;
       const int fb = 32 * nb + 8 * g + 4 * hh;
       const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
-      const v4f ah = ga[b & 1][q2][0], bh = ga[b & 1][q2][1], vh = ga[b & 1][q2][2];
+      const v4f ah = ga[b % GD][q2][0], bh = ga[b % GD][q2][1], vh = ga[b % GD][q2][2];
       v4f m;
       if constexpr (kPk) {
 #pragma unroll
@@ -573,7 +627,21 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   }
 #undef FUSED_GATHER
   FUSED_STAMP(5)
-  if constexpr (TAIL == 2) return;      // the edge output of this layer is never read
+  // requests of the workgroup's next tile that would otherwise be exposed at its top: the first ring slabs of e and the
+  // tile's scale.  The ring registers are dead after GEMM 1; issued here (MIS last layer) / behind the last MFMA of GEMM 2,
+  // they are covered by the last output phase.
+#define FUSED_NEXT_TILE_REQUESTS                                                       \
+  if constexpr (!L0) {                                                                 \
+    if (has_next) {                                                                    \
+      const int tile_n = (wt + wt_step) * WAVES + wave;                                \
+      ring_fill(tile_n);                                                               \
+      if constexpr (T::kScaled) tmax_cur = etmax_in[tile_n];                           \
+    }                                                                                  \
+  }
+  if constexpr (TAIL == 2) {      // the edge output of this layer is never read
+    FUSED_NEXT_TILE_REQUESTS
+    continue;
+  }
 
   // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
   constexpr float inv_h = 1.0f / 256.0f;
@@ -778,6 +846,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       FUSED_PIPE_END(t)
       if (t == NS1) { FUSED_STAMP(7) }
     }
+    if (qt == 3) { FUSED_NEXT_TILE_REQUESTS }
     // e <- e + W_o a + b_o  for the features 64 qt + 32 nbp + 8 g + 4 hh + 0..3 of this lane's edge
     if constexpr (skip_out) {
 #pragma unroll
@@ -857,9 +926,11 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   if constexpr ((ABL & 16) != 0) {
     if (dbg != nullptr && lane == 0) {
 #pragma unroll
-      for (int k = 0; k < 10; ++k) dbg[((long long)blockIdx.x * WAVES + wave) * 16 + k] = stamp[k];
+      for (int k = 0; k < 10; ++k) dbg[(long long)tile * 16 + k] = stamp[k];
     }
   }
+  }      // tiles of this workgroup
+#undef FUSED_NEXT_TILE_REQUESTS
 #undef FUSED_STAMP
 #undef FUSED_PIPE_BEGIN
 #undef FUSED_PIPE_END
@@ -894,7 +965,19 @@ hipError_t launch_fused_t(float* e, const float* node4, const int* row, const in
     if (er != hipSuccess) return er;
   }
   constexpr int WV = fused::geo_waves(NW);
-  const unsigned grid = (unsigned)((n_edges + 32 * WV - 1) / (32 * WV));
+  unsigned grid = (unsigned)((n_edges + 32 * WV - 1) / (32 * WV));
+  if constexpr ((OPT & 4096) != 0) {      // persistent workgroups: two per CU (what the LDS footprint admits), a multiple of 8
+    static std::atomic<int> resident{0};
+    int r = resident.load(std::memory_order_relaxed);
+    if (r == 0) {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 4)
+        cus = 256;
+      r = (2 * cus) / 8 * 8;
+      resident.store(r, std::memory_order_relaxed);
+    }
+    if (grid > (unsigned)r) grid = (unsigned)r;
+  }
   // profiling builds: FUSED_LDS_PAD extra bytes of dynamic LDS lower the number of co-resident workgroups per CU
   hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL, OPT>), dim3(grid), dim3(64 * WV),
                      fused::Geo<NW>::LDS_TOTAL + FUSED_LDS_PAD, stream,
@@ -916,6 +999,8 @@ hipError_t launch_fused_opt(A... args) {
     case 371: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 371>(args...);      // (A/B: no raised issue priority)
     case 883: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 883>(args...);      // (A/B: GEMM 1 slabs of e non-temporal too)
     case 1907: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 1907>(args...);    // (A/B: scalar element-wise arithmetic)
+    case 8051: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 8051>(args...);    // (A/B: production + persistent workgroups)
+    case 12147: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 12147>(args...);  // (A/B: production + gathers two batches ahead)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 #endif

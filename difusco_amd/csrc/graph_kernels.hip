@@ -281,27 +281,32 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 // partial of moment w of group g, the 4 chains are combined in a fixed order (deterministic).
 // group_stride_blocks: 1 when every block partial holds all 32 groups (row-major kernels); 8 when block b only
 // holds groups 4 (b % 8) .. 4 (b % 8) + 3 (tiled kernel).
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, const int* __restrict__ seg_ptr,
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* __restrict__ partial, const int* __restrict__ seg_ptr,
                                                           long long total_rows, int nblk, int ch_per_group,
                                                           int group_stride_blocks, float* __restrict__ stats,
                                                           double* __restrict__ sums_out) {
   // sums_out (one segment only): instead of the statistics, write the 32 x (sum, sum of squares) and the row count
   // [64] - the quantities a caller adds over the shards of a batch (difusco_step_args.gn_phase 1)
-  __shared__ double red[4][64];
+  // 16 chains (wavefronts) per moment: each adds every 16th block partial, the chains are combined in a fixed order
+  // (deterministic; 4 chains of 64 dependent loads made this kernel 19 us of pure latency)
+  __shared__ double red[16][64];
   const int seg = blockIdx.x;
-  const int c = threadIdx.x >> 6, gw = threadIdx.x & 63, g = gw >> 1;
+  const int c = threadIdx.x >> 6, gw = threadIdx.x & 63, g = gw >> 1, nch = blockDim.x >> 6;
   double acc = 0.0;
   if (group_stride_blocks == 1) {
-    for (int b = c; b < nblk; b += 4) acc += partial[((long long)seg * nblk + b) * 64 + gw];
+    for (int b = c; b < nblk; b += nch) acc += partial[((long long)seg * nblk + b) * 64 + gw];
   } else {
-    for (int b = (g >> 2) + 8 * c; b < nblk; b += 32) acc += partial[((long long)seg * nblk + b) * 64 + gw];
+    for (int b = (g >> 2) + 8 * c; b < nblk; b += 8 * nch) acc += partial[((long long)seg * nblk + b) * 64 + gw];
   }
   red[c][gw] = acc;
   __syncthreads();
   if (threadIdx.x < 32) {
     const int gg = threadIdx.x;
-    const double s = ((red[0][2 * gg] + red[1][2 * gg]) + red[2][2 * gg]) + red[3][2 * gg];
-    const double q = ((red[0][2 * gg + 1] + red[1][2 * gg + 1]) + red[2][2 * gg + 1]) + red[3][2 * gg + 1];
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nch; ++k) {
+      s += red[k][2 * gg];
+      q += red[k][2 * gg + 1];
+    }
     const long long rows = seg_ptr ? (long long)(seg_ptr[seg + 1] - seg_ptr[seg]) : total_rows;
     if (sums_out) {
       sums_out[2 * gg] = s;
@@ -666,7 +671,7 @@ hipError_t launch_head(int H, int C, const float* feat, const int* seg_ptr, int 
   if (gn_phase != 2) {
     DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((gn_partial_kernel<VEC>), grid, dim3(256), 0, stream, feat, seg_ptr,
                                                total_rows, partial))
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segments), dim3(256), 0, stream, partial, seg_ptr, total_rows, nblk, H / 32,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segments), dim3(1024), 0, stream, partial, seg_ptr, total_rows, nblk, H / 32,
                        1, stats, gn_phase == 1 ? gn_sums : (double*)nullptr);
     if (gn_phase == 1) return hipGetLastError();
   } else {
@@ -774,11 +779,11 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
     hipLaunchKernelGGL(gn_stats_from_sums_kernel, dim3(1), dim3(64), 0, stream, gn_sums, 8, stats);
   } else if (gn_tile) {   // statistics come from the last fused layer: no pass over feat
     hipLaunchKernelGGL(gn_tiles_reduce_kernel, dim3(256), dim3(256), 0, stream, gn_tile, n_tiles, partial);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, 256, 8, 1, stats,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 0, stream, partial, (const int*)nullptr, rows, 256, 8, 1, stats,
                        sums_out);
   } else {
     hipLaunchKernelGGL(gn_partial_tiled_kernel, dim3(nblk), dim3(256), 0, stream, feat, n_tiles, partial);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, (const int*)nullptr, rows, nblk, 8, 8, stats,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 0, stream, partial, (const int*)nullptr, rows, nblk, 8, 8, stats,
                        sums_out);
   }
   if (gn_phase == 1) return hipGetLastError();

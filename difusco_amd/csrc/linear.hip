@@ -166,10 +166,16 @@ static hipError_t launch_linear(const float* x, const float* w, const float* bia
 hipError_t linear_rows(const float* x, const float* w, const float* bias, const float* residual, float* y,
                        long long m, int k, int n_out, long long ldy, hipStream_t stream) {
   if (m <= 0) return hipSuccess;
+  // Feature block: the widest one that still gives the chip a workgroup per CU (node rows: 8,000 x 256 outputs are 63 row
+  // blocks - with 256-wide blocks 63 workgroups on 256 CUs, 52 us; with 64-wide blocks 252).  Every output element is the
+  // same k-ordered fma chain whatever the block width: results are bit-identical.
+  const long long rb = (m + 127) / 128;
+  const bool wide = n_out % 256 == 0 && rb * (n_out / 256) >= 256;
+  const bool mid = n_out % 128 == 0 && (n_out % 64 != 0 || rb * (n_out / 128) >= 256);
 #define DIFUSCO_LIN_CASE(KK, BKK)                                                                         \
   if (k == KK) {                                                                                          \
-    if (n_out % 256 == 0) return launch_linear<KK, 256, BKK>(x, w, bias, residual, y, m, n_out, ldy, stream); \
-    if (n_out % 128 == 0) return launch_linear<KK, 128, BKK>(x, w, bias, residual, y, m, n_out, ldy, stream); \
+    if (wide) return launch_linear<KK, 256, BKK>(x, w, bias, residual, y, m, n_out, ldy, stream);         \
+    if (mid) return launch_linear<KK, 128, BKK>(x, w, bias, residual, y, m, n_out, ldy, stream);          \
     if (n_out % 64 == 0) return launch_linear<KK, 64, BKK>(x, w, bias, residual, y, m, n_out, ldy, stream);   \
     if (n_out % 32 == 0) return launch_linear<KK, 32, BKK>(x, w, bias, residual, y, m, n_out, ldy, stream);   \
     return hipErrorInvalidValue;                                                                          \

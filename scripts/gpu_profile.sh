@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 REPO=$PWD
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 KEY=${2:-tsp1000:800000:fused-fp16x3}
 EXTRA=${PROF_BENCH_ARGS:-}
 BENCH_ARGS="--steps 5 --warmup 2 --cpu-steps 0 --no-profile --no-exact-fp32 $EXTRA"

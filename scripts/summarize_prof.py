@@ -11,7 +11,7 @@ import os
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 # key of the profiled run in profiles/<round>/pmc_traffic.json: "<workload>:<edges on rank 0>:<variant>" (bench.py looks its
 # own run up under exactly this key and reports traffic = null when the run was never profiled)
 run_key = sys.argv[2] if len(sys.argv) > 2 else "tsp1000:800000:fused-fp16x3"
