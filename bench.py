@@ -38,22 +38,24 @@ def log(*a):
 
 def pmc_traffic_bytes(kernel_name, workload, n_edges, variant):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE doubled per the
-    gfx950 half-count correction + WRITE_SIZE; scripts/gpu_profile.sh + scripts/summarize_prof.py).  The table
-    profiles/r02/pmc_traffic.json is keyed by "<workload>:<edges on rank 0>:<variant>", i.e. by the exact run the
-    counters were collected on; a run with no profile of its own reports None (never another workload's bytes)."""
-    path = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-    try:
-        table = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    entry = table.get(f"{workload}:{n_edges}:{variant}")
-    if not entry:
-        return None
-    for key, val in entry.items():
-        if key in kernel_name:
-            return {"bytes_per_launch": val["fetch_bytes"] + val["write_bytes"], "fetch_bytes": val["fetch_bytes"],
-                    "write_bytes": val["write_bytes"],
-                    "source": f"profiles/r02/pmc_traffic.json[{workload}:{n_edges}:{variant}] (rocprofv3 --pmc)"}
+    gfx950 half-count correction + WRITE_SIZE; scripts/gpu_profile.sh + scripts/summarize_prof.py).  The tables
+    profiles/r03/pmc_traffic.json (this round's kernel), then profiles/r02/pmc_traffic.json, are keyed by
+    "<workload>:<edges on rank 0>:<variant>", i.e. by the exact run the counters were collected on; a run with no profile
+    of its own reports None (never another workload's bytes)."""
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        try:
+            table = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        entry = table.get(f"{workload}:{n_edges}:{variant}")
+        if not entry:
+            continue
+        for key, val in entry.items():
+            if key in kernel_name:
+                return {"bytes_per_launch": val["fetch_bytes"] + val["write_bytes"], "fetch_bytes": val["fetch_bytes"],
+                        "write_bytes": val["write_bytes"],
+                        "source": f"profiles/{rnd}/pmc_traffic.json[{workload}:{n_edges}:{variant}] (rocprofv3 --pmc)"}
     return None
 
 
