@@ -56,5 +56,26 @@ for n, k, reps, cpu in ((1000, 100, 20, True), (10000, 100, 5, False)):
         dtc = time.perf_counter() - t0
         case["two_opt"]["cpu_baseline"] = {"ms_per_move": 1e3 * dtc / max(ref_moves, 1), "cores": 1, "kind": "port",
                                            "sample": f"{ref_moves} moves of the numpy restatement ({dtc:.2f} s)"}
+    # MCTS heatmap text (tsp_mcts/convert_numpy_to_txt.py): numeric part on the GPU, %.6f formatting + file on the host;
+    # beside it the host numpy sweeps of the same module (the reference converter itself needs five dense N x N arrays)
+    from difusco_amd import formats
+    import tempfile
+    pts32 = torch.from_numpy(pts.astype(np.float32)).to(dev)
+    list(formats.mcts_heatmap_rows_gpu(heat_d, ei_d, pts32, n, 0.02, device=dev))               # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_rows = sum(1 for _ in formats.mcts_heatmap_rows_gpu(heat_d, ei_d, pts32, n, 0.02, device=dev))
+    t_rows = time.perf_counter() - t0
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        t0 = time.perf_counter()
+        path = formats.write_mcts_heatmap(heat_d, pts32, n, tmp, 0, edge_index=ei_d, use_gpu=True)
+        t_file = time.perf_counter() - t0
+        size = os.path.getsize(path)
+    case["mcts_text"] = {"rows_to_host_s": t_rows, "rows": n_rows, "file_s": t_file, "file_bytes": size,
+                         "note": "rows_to_host = GPU numeric part + device-to-host copy of the N^2 floats; file = + %.6f formatting"}
+    if cpu:
+        t0 = time.perf_counter()
+        sum(1 for _ in formats.mcts_heatmap_rows(heat, ei, pts.astype(np.float32), n, 0.02))
+        case["mcts_text"]["host_numpy_rows_s"] = time.perf_counter() - t0
     out["cases"].append(case)
 print(json.dumps(out))
