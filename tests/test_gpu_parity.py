@@ -1072,6 +1072,45 @@ def test_default_engine_at_adversarial_weight_scales(dev, kind, groups, exp):
         assert (prob.cpu().reshape(-1) - ref_prob.reshape(-1)).abs().max().item() < TOL
 
 
+@pytest.mark.parametrize("variant", ["unfused", "no_folds", "bf16x3", "dense_b2", "h128_unfused"])
+@pytest.mark.parametrize("groups,exp", [(("abc",), -13), (("out",), 5), (("edge_embed",), -8), (("abc", "uv", "out"), -10),
+                                        (("node_embed", "edge_embed"), 10)])
+def test_other_paths_at_adversarial_weight_scales(dev, variant, groups, exp):
+    """The operand scaling on the paths the default engine does not take: the unfused kernel sequence with fp16 planes (row
+    scales computed by an extra pass: `escale`), the fused path without the first-/last-layer folds (e0 written by the table
+    kernel + `tile_absmax`, statistics by a separate pass), bf16 planes (unscaled by design), dense mode with two samples
+    (per-sample statistic segments -> unfused), and H = 128."""
+    from difusco_amd import TSPModel, _lib
+    H, Lyr = (128, 3) if variant == "h128_unfused" else (256, 6)
+    p = _scaled_params(O.init_params(H, Lyr, 2, seed=78), groups, 2.0 ** exp, Lyr)
+    g = torch.Generator().manual_seed(8)
+    t, tt = 500, 469
+    kw = {"unfused": dict(fused=False), "no_folds": dict(flags=_lib.FLAG_NO_L0_FOLD | _lib.FLAG_NO_TAIL_FOLD),
+          "bf16x3": dict(precision="bf16x3"), "dense_b2": {}, "h128_unfused": dict(fused=False)}[variant]
+    if variant == "dense_b2":
+        pts = torch.rand(2, 14, 2, generator=g)
+        xt = (torch.randn(2, 14, 14, generator=g) > 0).float()
+        u = torch.rand(2, 14, 14, generator=g)
+        _, ref, ref_prob = O.tsp_categorical_denoise_step(p, O.CategoricalTables(), pts, xt, t, None, tt, uniform=u, return_aux=True)
+        m = TSPModel(_args("categorical", sparse_factor=-1, H=H, L=Lyr), p, device=dev)
+        _, out, prob = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, None, target_t=np.array([tt]),
+                                                  uniform=u, return_aux=True)
+        ref = ref.permute(0, 2, 3, 1)                      # oracle [B,C,V,V] -> [B,V,V,C]
+    else:
+        pts, ei = O.tsp_instance(60, 10, seed=4)
+        pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
+        xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
+        u = torch.rand(ei.shape[1], generator=g)
+        _, ref, ref_prob = O.tsp_categorical_denoise_step(p, O.CategoricalTables(), pts, xt, t, ei, tt, uniform=u, return_aux=True)
+        m = TSPModel(_args("categorical", 10, H=H, L=Lyr), p, device=dev, **kw)
+        _, out, prob = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev),
+                                                  target_t=np.array([tt]), uniform=u, return_aux=True)
+    err = (out.cpu().reshape(ref.shape) - ref).abs().max().item()
+    print(f"{variant} {'+'.join(groups)} x 2^{exp}: network output L_inf {err:.2e}")
+    assert torch.isfinite(out).all() and err < TOL, err
+    assert (prob.cpu().reshape(-1) - ref_prob.reshape(-1)).abs().max().item() < TOL
+
+
 @pytest.mark.parametrize("task", ["tsp", "mis"])
 def test_free_running_trajectory_fused_h256(dev, task):
     """test_free_running_trajectory on the DEFAULT path (H=256, fused kernel, fp16x3): GPU and oracle each feed their
