@@ -294,6 +294,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
   const bool fused = H == 256 && !a->no_fusion && E > 0 && a->n_segments == 1 &&
                      (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
   if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
+  if (fused && N >= (1 << 20))      // the full-line neighbour-table gathers address node rows by 32-bit byte offsets (4 KB per node)
+    return fail(DIFUSCO_EUNSUPPORTED, "fused path: n_nodes must be < 2^20 per call (got %lld); set no_fusion", (long long)N);
   const int64_t E_pad = (E + 255) / 256 * 256;
   // first layer: when the edge input is a table lookup (categorical TSP: embedding of the bit; MIS: zeros) the fused
   // kernel takes it from the table and the pass that would write e0 to HBM is skipped
@@ -513,6 +515,7 @@ int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int3
     return fail(DIFUSCO_EINVAL, "null pointer");
   if (precision == DIFUSCO_PREC_FP16X3 && !scales)
     return fail(DIFUSCO_EINVAL, "fused kernel, FP16X3: the operand-scale record of the layer is required");
+  if (n_nodes >= (1 << 20)) return fail(DIFUSCO_EUNSUPPORTED, "fused kernel: n_nodes must be < 2^20");
   const long long off = precision == DIFUSCO_PREC_FP16X3 ? 3LL * 256 * 256 : 0;
   float* part = reinterpret_cast<float*>(scratch);
   float* direct = part + (fused_part_floats(n_edges) + 63) / 64 * 64;

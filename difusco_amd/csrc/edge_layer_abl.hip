@@ -15,20 +15,21 @@ hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS) {
     case 8: return launch_fused_t<FFp16, 8, FUSED_NW>(ABL_ARGS, ABL_TAIL);      // no GEMM 2
     case 15: return launch_fused_t<FFp16, 15, FUSED_NW>(ABL_ARGS, ABL_TAIL);    // GEMM 1 + weight streaming only
     case 16: return launch_fused_t<FFp16, 16, FUSED_NW>(ABL_ARGS, ABL_TAIL);    // production code + phase timestamps
-    case 17: return launch_fused_t<FFp16, 15, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // 15 with the production options
-    case 18: return launch_fused_t<FFp16, 16, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // 16 (phase stamps), production options
-    case 22: return launch_fused_t<FFp16, 16 + 32768, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // stamps, no e stream
-    case 23: return launch_fused_t<FFp16, 16 + 16384, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // stamps, no stage refills / barriers
-    case 24: return launch_fused_t<FFp16, 16 + 1, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);       // stamps, no gathers
-    case 27: return launch_fused_t<FFp16, 16 + 65536, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);     // stamps, stage requests not waited for
-    case 28: return launch_fused_t<FFp16, 16 + 131072, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);    // stamps, no stage barrier
-    case 29: return launch_fused_t<FFp16, 16 + 196608, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);    // stamps, neither (requests still issued)
-    case 30: return launch_fused_t<FFp16, 16 + 128, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);       // stamps, no B h[i] gathers
-    case 31: return launch_fused_t<FFp16, 16 + 256, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);       // stamps, no A h[j] / V h[j] gathers
+    case 17: return launch_fused_t<FFp16, 15, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // 15 with the production options
+    case 18: return launch_fused_t<FFp16, 16, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // 16 (phase stamps), production options (full-line gathers)
+    case 19: return launch_fused_t<FFp16, 16, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // stamps, round 2's options (register gathers)
+    case 22: return launch_fused_t<FFp16, 16 + 32768, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // stamps, no e stream
+    case 23: return launch_fused_t<FFp16, 16 + 16384, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // stamps, no stage refills / barriers
+    case 24: return launch_fused_t<FFp16, 16 + 1, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);       // stamps, no gathers
+    case 27: return launch_fused_t<FFp16, 16 + 65536, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);     // stamps, stage requests not waited for
+    case 28: return launch_fused_t<FFp16, 16 + 131072, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);    // stamps, no stage barrier
+    case 29: return launch_fused_t<FFp16, 16 + 196608, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);    // stamps, neither (requests still issued)
+    case 30: return launch_fused_t<FFp16, 16 + 128, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);       // stamps, no B h[i] gathers
+    case 31: return launch_fused_t<FFp16, 16 + 256, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);       // stamps, no A h[j] / V h[j] gathers
     case 32:      // stamps, LAST layer of a TSP step (no V gathers / gate / neighbour sum; GroupNorm partial sums go to `part`)
-      return launch_fused_t<FFp16, 16, FUSED_NW, false, true, 1, FUSED_OPT>(ABL_ARGS, nullptr, nullptr, nullptr, part, scales, etmax_in, nullptr);
+      return launch_fused_t<FFp16, 16, FUSED_NW, false, true, 1, FUSED_OPT_R2>(ABL_ARGS, nullptr, nullptr, nullptr, part, scales, etmax_in, nullptr);
     case 33:      // stamps, FIRST layer (two-row table instead of e and GEMM 1; the table rows are taken from b_c .. for timing only)
-      return launch_fused_t<FFp16, 16, FUSED_NW, true, false, 0, FUSED_OPT>(ABL_ARGS, node4, nullptr, nullptr, nullptr, scales, etmax_in, etmax_out);
+      return launch_fused_t<FFp16, 16, FUSED_NW, true, false, 0, FUSED_OPT_R2>(ABL_ARGS, node4, nullptr, nullptr, nullptr, scales, etmax_in, etmax_out);
     default: return hipErrorInvalidValue;
   }
 #undef ABL_ARGS

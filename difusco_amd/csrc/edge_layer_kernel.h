@@ -123,7 +123,10 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //   bit 8  GEMM 1 input slabs of e through a buffer resource (kBufRing below).
   //   bit 9  raised issue priority outside the GEMM phases;  bit 10  default cache policy for the GEMM 1 slabs of e.
   //   bit 11 element-wise arithmetic on register pairs (kPk below).
-  // Production = 3955 (bits 0, 1, 4, 5, 6, 8, 9, 10, 11): +16 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
+  //   bit 12 persistent workgroups, bit 13 gathers two batches ahead (both measured slower, profiling library only);
+  //   bit 14 FULL-LINE neighbour-table gathers through LDS-DMA (+3.4 %, see the gather phase), bit 15 two units + counted waits (no
+  //          further gain, profiling library only).
+  // Production = 20339 (bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14).  Bits 0-11 = 3955: +16 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
   // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5, 8-10 do not change a result bit; bit 6
   // changes the summation order of the LayerNorm statistics and bit 11 where the compiler contracts multiply-adds (fp32
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c_planes), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(o_planes), 0, 0x7fffffff, 0x00020000);
   const int plane_bytes = (int)plane_stride * 2;
+  constexpr bool kLate16 = (OPT & 16384) != 0 && (OPT & 32768) != 0 && TAIL != 2;      // see OPT bit 15 at the gather phase
   constexpr int FIRST_T = L0 ? NS1 : 0;                       // first stage of a tile (layer 0 has no GEMM 1)
   constexpr int LAST_T = TAIL == 2 ? NS1 - 1 : NSTAGE - 1;    // last stage of a tile (MIS last layer: no GEMM 2)
   static_assert(((LAST_T + 1 - FIRST_T) & 1) == 0, "an even number of stages per tile keeps the buffer parity");
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   }
 #define FUSED_PIPE_BEGIN(t)                                         \
   if constexpr (!kNoSync) {                                         \
-    if ((t) < LAST_T) {                                             \
+    if ((t) < LAST_T && !(kLate16 && (t) + 1 == NS1)) {             \
       FUSED_DMA_STAGE((t) + 1)                                      \
       __builtin_amdgcn_sched_barrier(0);                            \
     } else if (has_next) {                                          \
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       ring_fill(wt * WAVES + wave);
       if constexpr (T::kScaled) tmax_cur = etmax_in[wt * WAVES + wave];      // (wave uniform: scalar load)
     }
-    FUSED_DMA_STAGE(FIRST_T)
+    if constexpr (!(kLate16 && L0)) { FUSED_DMA_STAGE(FIRST_T) }
   }
   if (tid < H) {
     prm[P_BC * H + tid] = b_c[tid];
@@ -541,6 +545,189 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       }                                                                               \
     }                                                                                 \
   }
+  // one aggregation round: the gated messages of 64 features (two blocks) of all 32 edges sit in the wave's scratch
+#define FUSED_AGG_ROUND(rnd)                                                                                                 \
+      __builtin_amdgcn_wave_barrier();                                                                                       \
+      if constexpr (!(ablate & 2)) {                                                                                         \
+        const int f = 64 * (rnd) + lane;                                                                                       \
+        /* two halves of 16 rows: 32 values in flight at once is the register peak of the kernel (128 accumulators + the */  \
+        /* gather buffers are live here) and made the compiler spill accumulators */                                         \
+        float accv = 0.0f;                                                                                                   \
+_Pragma("unroll")                                                                                                         \
+        for (int half = 0; half < 2; ++half) {                                                                               \
+          float v[16];                                                                                                       \
+_Pragma("unroll")                                                                                                         \
+          for (int k = 0; k < 16; ++k) v[k] = scr[(16 * half + k) * SCR_STRIDE + lane];                                      \
+_Pragma("unroll")                                                                                                         \
+          for (int kk = 0; kk < 16; ++kk) {                                                                                  \
+            const int k = 16 * half + kk;                                                                                    \
+            if (k > 0 && ((bnd >> k) & 1u)) {                      /* wave-uniform branch */                                 \
+              const int node = __builtin_amdgcn_readlane(i_node, k - 1);                                                     \
+              float* dst = (k == first_end) ? part0 : direct + (long long)node * H;                                          \
+              dst[f] = accv;                                                                                                 \
+              accv = 0.0f;                                                                                                   \
+            }                                                                                                                \
+            accv += v[kk];                                                                                                   \
+          }                                                                                                                  \
+          __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        }                                                                                                                    \
+        float* dst = (first_end == 32) ? part0 : part1;                                                                      \
+        dst[f] = accv;                                                                                                       \
+      }                                                                                                                      \
+      __builtin_amdgcn_wave_barrier();
+  // OPT bit 14 (experiment): A h[j] / V h[j] by FULL-LINE gathers.  With lane = edge every gather instruction touches 32 rows x
+  // 32 B: 2,048 line look-ups per tile for 512 distinct lines.  Here a (table, block nb) unit - 32 rows x 128 B = the 32 features
+  // of block nb - is fetched by four LDS-DMA instructions (lane L: row 8 p + L / 8, 16-byte chunk (L % 8) ^ swz(row), i.e. eight
+  // full lines per instruction) into the wave's share of weight buffer 1, which is idle between the end of GEMM 1 and the wave's
+  // own request of stage 17 (its two 2-KB piece areas: rows 0-15 | 16-31), and read back as four ds_read_b128 per lane
+  // (chunk 2 g + hh at position (2 g + hh) ^ swz(edge): conflict free with swz(r) = ((r >> 1) & 3) | ((r >> 4) & 1) << 2).
+  // One buffer, the two tables alternate: A(nb) is read, V(nb) requested, the gate's e' / sigmoid computed, V(nb) read,
+  // A(nb + 1) requested, the messages formed.  Every wait is vmcnt(0): stores share the counter on gfx9.
+  constexpr bool kFL = (OPT & 16384) != 0;
+  static_assert(!kFL || (kPk && (ablate & 0x3EF) == 0 && !kG2), "OPT bit 14 is written for the production arithmetic");
+  // OPT bit 15 (with bit 14): TWO units - A in the wave's share of buffer 1, V in its share of buffer 0 - so that the next block
+  // of a table is requested as soon as the current one has been read (a whole block of cover instead of half).  Buffer 0 is
+  // free because GEMM 2's first weight stage is then requested AFTER the gather phase (kLate16; the LayerNorm phase covers it)
+  // and met by one extra workgroup barrier in front of GEMM 2.  Waits are counted: at every wait the operations allowed to stay
+  // in flight are the NEWEST loads (the other table's block + the B h[i] rows), and loads return in order, so an old
+  // request cannot be pending when the count is reached - whatever the neighbour-sum stores (same counter) do.
+  constexpr bool kFL2 = kFL && (OPT & 32768) != 0;
+  static_assert(!kFL2 || !kPersist, "bits 12 and 15 are not combined");
+  if constexpr (kFL) {
+    const int rsel = lane >> 3, cc = lane & 7;
+    auto swz = [](int r) { return ((r >> 1) & 3) | (((r >> 4) & 1) << 2); };
+    unsigned src_off[4];
+#pragma unroll
+    for (int p4 = 0; p4 < 4; ++p4) {
+      const int r = 8 * p4 + rsel;
+      const int jr = __shfl(j, r, 64);
+      src_off[p4] = (unsigned)jr * (unsigned)(4 * H * 4) + (unsigned)((cc ^ swz(r)) * 16);
+    }
+    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(node4), 0, 0xffffffff, 0x00020000);
+    // unit u: rows 0-15 in the plane-0 piece area, rows 16-31 in the plane-1 piece area of this wave, buffer 1 - u
+    unsigned short* const ua0 = wbuf + BUF + (PP * wave) * 512;
+    unsigned short* const ua1 = wbuf + BUF + PLANE + (PP * wave) * 512;
+    unsigned short* const ub0 = wbuf + (PP * wave) * 512;
+    unsigned short* const ub1 = wbuf + PLANE + (PP * wave) * 512;
+    const int rd_row = ((l31 & 16) ? PLANE * 2 : 0) + (l31 & 15) * 128;      // byte offset of this lane's row inside a unit
+    const unsigned char* const rd_a = reinterpret_cast<const unsigned char*>(ua0) + rd_row;
+    const unsigned char* const rd_b = reinterpret_cast<const unsigned char*>(ub0) + rd_row;
+    int rd_pos[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rd_pos[g] = ((2 * g + hh) ^ swz(l31)) * 16;
+    // table: 1 = V (float offset H), 2 = A (float offset 2 H) of the node4 row; unit 0 = buffer 1 areas, 1 = buffer 0 areas
+#define FUSED_FL_REQUEST(table, nb_, unit)                                                                                  \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4)                                                                      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_n,                                                                      \
+          (__attribute__((address_space(3))) void*)(((unit) ? ((p4 >> 1) ? ub1 : ub0) : ((p4 >> 1) ? ua1 : ua0)) + (p4 & 1) * 512), \
+          16, src_off[p4], (table) * H * 4 + (nb_) * 128, 0, 0);                                                          \
+  }
+#define FUSED_FL_WAIT(n)                                                          \
+  __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14));           \
+  __builtin_amdgcn_sched_barrier(0);                                              \
+  asm volatile("" ::: "memory");
+#define FUSED_FL_READ(dst, unit)                                                                      \
+  {                                                                                                   \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                     \
+      dst[g] = *reinterpret_cast<const v4f*>(((unit) ? rd_b : rd_a) + rd_pos[g]);                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+    // B h[i] rows through the same buffer resource (MUBUF like the LDS-DMA requests: one in-order load queue for the counted waits)
+    v4f bh_[2][4];
+    const int b_voff = i_node * (4 * H * 4) + hh * 16;
+#define FUSED_FL_B(nb_, buf)                                                                          \
+  {                                                                                                   \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                     \
+      bh_[buf][g] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_n, b_voff, (3 * H + 32 * (nb_) + 8 * g) * 4, 0)); \
+  }
+    FUSED_FL_B(0, 0)
+    FUSED_FL_REQUEST(2, 0, 0)
+    if constexpr (kFL2 && TAIL != 1) { FUSED_FL_REQUEST(1, 0, 1) }
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const int nq = nb & 1;
+      if (nb + 1 < 8) {
+        if (((nb + 1) & 1) == 0) FUSED_FL_B(nb + 1, 0) else FUSED_FL_B(nb + 1, 1)
+        if constexpr (kFL2 && TAIL == 1) {      // A alternates between the two units, one block ahead
+          if (((nb + 1) & 1) == 0) FUSED_FL_REQUEST(2, nb + 1, 0) else FUSED_FL_REQUEST(2, nb + 1, 1)
+        }
+      }
+      v4f ah_q[4], vh_q[4];
+      v2f sg_q[4][2];
+      if constexpr (kFL2) {
+        if (nb + 1 < 8) { FUSED_FL_WAIT(8) }           // in flight: the other table's block (V(nb) | A(nb+1)) + B(nb+1)
+        else if (TAIL != 1) { FUSED_FL_WAIT(4) }       // V(7)
+        else { FUSED_FL_WAIT(0) }
+      } else {
+        FUSED_FL_WAIT(0)
+      }
+      if constexpr (kFL2 && TAIL == 1) {
+        if ((nb & 1) == 0) FUSED_FL_READ(ah_q, 0) else FUSED_FL_READ(ah_q, 1)
+      } else {
+        FUSED_FL_READ(ah_q, 0)
+      }
+      if constexpr (kFL2) {
+        if constexpr (TAIL != 1) {
+          if (nb + 1 < 8) { FUSED_FL_REQUEST(2, nb + 1, 0) }
+        }
+      } else {
+        if constexpr (TAIL != 1) { FUSED_FL_REQUEST(1, nb, 0) }
+        else if (nb + 1 < 8) { FUSED_FL_REQUEST(2, nb + 1, 0) }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fb = 32 * nb + 8 * g + 4 * hh;
+        const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int r = 4 * g + 2 * h2;
+          v2f ce;
+          if constexpr (T::kScaled && !L0) ce = DIFUSCO_PAIR(acc1[nb], r) * v2f{inv1, inv1} + DIFUSCO_PAIR(bc, 2 * h2);
+          else ce = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(bc, 2 * h2);
+          const v2f ev = (DIFUSCO_PAIR(ah_q[g], 2 * h2) + DIFUSCO_PAIR(bh_[nb & 1][g], 2 * h2)) + ce;
+          acc1[nb][r] = ev[0];
+          acc1[nb][r + 1] = ev[1];
+          s1k[h2] += ev;
+          if constexpr (TAIL != 1) sg_q[g][h2] = fast_sigmoid2(ev);
+        }
+      }
+      if constexpr (TAIL != 1) {
+        if constexpr (kFL2) {
+          if (nb + 1 < 8) { FUSED_FL_WAIT(8) }         // in flight: B(nb+1), A(nb+1)
+          else { FUSED_FL_WAIT(0) }
+          FUSED_FL_READ(vh_q, 1)
+        } else {
+          FUSED_FL_WAIT(0)
+          FUSED_FL_READ(vh_q, 0)
+          if (nb + 1 < 8) { FUSED_FL_REQUEST(2, nb + 1, 0) }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          v4f m;
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const v2f sg = sg_q[g][h2] * DIFUSCO_PAIR(vh_q[g], 2 * h2);
+            m[2 * h2] = valid ? sg[0] : 0.0f;
+            m[2 * h2 + 1] = valid ? sg[1] : 0.0f;
+          }
+          *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
+        }
+        if (nq == 1) { FUSED_AGG_ROUND(nb >> 1) }
+        // (after the stores of the round: the newest operations at the next wait must be loads)
+        if constexpr (kFL2) {
+          if (nb + 1 < 8) { FUSED_FL_REQUEST(1, nb + 1, 1) }
+        }
+      }
+    }
+    // GEMM 2's first weight stage, requested now that buffer 0 is free again (its landing is met in front of GEMM 2)
+    if constexpr (kFL2 && TAIL != 2) { FUSED_DMA_STAGE(NS1) }
+#undef FUSED_FL_REQUEST
+#undef FUSED_FL_WAIT
+#undef FUSED_FL_READ
+#undef FUSED_FL_B
+  } else {
   FUSED_GATHER(0, 0)
   if constexpr (kG2) { FUSED_GATHER(1, 1) }
 #pragma unroll
@@ -594,38 +781,12 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
       // 64 features (blocks 2 rnd, 2 rnd + 1) of all 32 edges are in the scratch: segmented column sums,
       // lane = feature 64 rnd + lane.  The first segment of a tile may continue from the previous tile and
       // the last into the next one (part[tile][0|1]); inner segments are complete (direct[node]).
-      const int rnd = b >> 2;
-      __builtin_amdgcn_wave_barrier();
-      if constexpr (!(ablate & 2)) {
-        const int f = 64 * rnd + lane;
-        // two halves of 16 rows: 32 values in flight at once is the register peak of the kernel (128 accumulators + the
-        // gather buffers are live here) and made the compiler spill accumulators
-        float accv = 0.0f;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          float v[16];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) v[k] = scr[(16 * half + k) * SCR_STRIDE + lane];
-#pragma unroll
-          for (int kk = 0; kk < 16; ++kk) {
-            const int k = 16 * half + kk;
-            if (k > 0 && ((bnd >> k) & 1u)) {                      // wave-uniform branch
-              const int node = __builtin_amdgcn_readlane(i_node, k - 1);
-              float* dst = (k == first_end) ? part0 : direct + (long long)node * H;
-              dst[f] = accv;
-              accv = 0.0f;
-            }
-            accv += v[kk];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        float* dst = (first_end == 32) ? part0 : part1;
-        dst[f] = accv;
-      }
-      __builtin_amdgcn_wave_barrier();
+      FUSED_AGG_ROUND(b >> 2)
     }
   }
+  }      // !kFL
 #undef FUSED_GATHER
+#undef FUSED_AGG_ROUND
   FUSED_STAMP(5)
   // requests of the workgroup's next tile that would otherwise be exposed at its top: the first ring slabs of e and the
   // tile's scale.  The ring registers are dead after GEMM 1; issued here (MIS last layer) / behind the last MFMA of GEMM 2,
@@ -786,6 +947,12 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #pragma unroll
     for (int kc = 0; kc < SPQ; ++kc) {
       const int t = NS1 + qt * SPQ + kc;
+      if constexpr (kLate16) {
+        if (t == NS1) {      // the first stage of GEMM 2 was requested after the gather phase: every wave's pieces have landed
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          __syncthreads();
+        }
+      }
       FUSED_PIPE_BEGIN(t)
       if (kc == SPQ - 1 && !skip_gemm2 && !skip_out) {
 #pragma unroll
@@ -947,7 +1114,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #define FUSED_DBG nullptr
 #define FUSED_START_DELAY 0
 #endif
-#define FUSED_OPT 3955       // production scheduling options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10, 11 of the kernel)
+#define FUSED_OPT 20339      // production options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14 of the kernel)
+#define FUSED_OPT_R2 3955    // round 2's production set (register gathers): what the gather / neighbour-sum ablation masks are written for
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
 template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0, int OPT = 0>
@@ -1001,6 +1169,8 @@ hipError_t launch_fused_opt(A... args) {
     case 1907: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 1907>(args...);    // (A/B: scalar element-wise arithmetic)
     case 8051: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 8051>(args...);    // (A/B: production + persistent workgroups)
     case 12147: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 12147>(args...);  // (A/B: production + gathers two batches ahead)
+    case 3955: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 3955>(args...);    // (A/B: round 2's production: register gathers)
+    case 53107: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 53107>(args...);  // (A/B: ... + two units, counted waits)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 #endif
