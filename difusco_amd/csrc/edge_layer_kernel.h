@@ -334,6 +334,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   const int tile = wt * WAVES + wave;
   const int s_raw = tile * 32 + l31;
   const bool valid = s_raw < n_edges;
+  const bool tile_full = (tile + 1) * 32 <= n_edges;      // (wave uniform)
   const int s = valid ? s_raw : n_edges - 1;   // lanes past the end redo the last edge and are masked out
   // e is stored TILED ("MFMA native", see edge_tiled_offset in kernels.h): per 32-edge tile the 1 KiB that one
   // wave instruction touches is contiguous, so every access below is a fully coalesced 1 KiB transaction
@@ -703,16 +704,30 @@ _Pragma("unroll")                                                               
           FUSED_FL_READ(vh_q, 0)
           if (nb + 1 < 8) { FUSED_FL_REQUEST(2, nb + 1, 0) }
         }
+        if (tile_full) {      // (wave uniform) every tile but the last of a launch: no per-element selects
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          v4f m;
+          for (int g = 0; g < 4; ++g) {
+            v4f m;
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const v2f sg = sg_q[g][h2] * DIFUSCO_PAIR(vh_q[g], 2 * h2);
-            m[2 * h2] = valid ? sg[0] : 0.0f;
-            m[2 * h2 + 1] = valid ? sg[1] : 0.0f;
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const v2f sg = sg_q[g][h2] * DIFUSCO_PAIR(vh_q[g], 2 * h2);
+              m[2 * h2] = sg[0];
+              m[2 * h2 + 1] = sg[1];
+            }
+            *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
           }
-          *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            v4f m;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+              const v2f sg = sg_q[g][h2] * DIFUSCO_PAIR(vh_q[g], 2 * h2);
+              m[2 * h2] = valid ? sg[0] : 0.0f;
+              m[2 * h2 + 1] = valid ? sg[1] : 0.0f;
+            }
+            *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
+          }
         }
         if (nq == 1) { FUSED_AGG_ROUND(nb >> 1) }
         // (after the stores of the round: the newest operations at the next wait must be loads)
@@ -1171,6 +1186,7 @@ hipError_t launch_fused_opt(A... args) {
     case 12147: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 12147>(args...);  // (A/B: production + gathers two batches ahead)
     case 3955: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 3955>(args...);    // (A/B: round 2's production: register gathers)
     case 53107: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 53107>(args...);  // (A/B: ... + two units, counted waits)
+    case 19827: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 19827>(args...);  // (A/B: production without the raised issue priority)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 #endif
