@@ -5,7 +5,7 @@ import os
 
 from .build import LIB_PATH, PROF_LIB_PATH
 
-FLAG_NO_L0_FOLD, FLAG_NO_TAIL_FOLD = 1, 2      # difusco_step_args.flags
+FLAG_NO_L0_FOLD, FLAG_NO_TAIL_FOLD, FLAG_CHECK_FINITE = 1, 2, 4      # difusco_step_args.flags
 
 ABI_VERSION = 8
 TASK_TSP, TASK_MIS = 0, 1

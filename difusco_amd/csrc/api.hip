@@ -435,6 +435,23 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                        LW(l, DIFUSCO_WL_OUT_B), ws.e, ws.e))
   }
 
+  // DIFUSCO_FLAG_CHECK_FINITE: count inf / nan in the outputs (the statistics scratch is free after the head), synchronise
+  auto finish = [&]() -> int {
+    if ((a->flags & DIFUSCO_FLAG_CHECK_FINITE) == 0 || a->gn_phase == 1) return DIFUSCO_OK;
+    unsigned* cnt = reinterpret_cast<unsigned*>(ws.partial);
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(unsigned), st));
+    HIP_TRY(launch_count_nonfinite(a->xt_out, out_rows, cnt, st));
+    HIP_TRY(launch_count_nonfinite(ws.stats, (long long)a->n_segments * 64, cnt, st));   // head GroupNorm mean / rstd: nan as soon as the
+                                                                                         // final state holds one (a sampled bit hides it)
+    HIP_TRY(launch_count_nonfinite(a->pred_out, out_rows * C, cnt, st));
+    HIP_TRY(launch_count_nonfinite(a->prob_out, a->diffusion == DIFUSCO_CATEGORICAL ? out_rows : 0, cnt, st));
+    unsigned bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, cnt, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bad) return fail(DIFUSCO_ENONFINITE, "denoise step produced %u non-finite output values", bad);
+    return DIFUSCO_OK;
+  };
+
   // head + posterior (gnn_encoder.py:400-401 / :412-413, pl_tsp_model.py:133-137, pl_meta_model.py:102-175)
   if (fused && tsp) {
     PROF(PROF_HEAD, launch_head_tiled(C, ws.e, E, gn_blocks_for(out_rows) < 8 ? 8 : gn_blocks_for(out_rows) / 8 * 8,
@@ -442,7 +459,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                       G(DIFUSCO_W_OUT_CONV_W), G(DIFUSCO_W_OUT_CONV_B), a->perm, a->xt, a->post,
                                       a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st,
                                       gn_fold ? ws.gn_tile : nullptr, a->gn_phase, a->gn_sums))
-    return DIFUSCO_OK;
+    return finish();
   }
   PROF(PROF_HEAD, launch_head(H, C, tsp ? ws.e : ws.h, a->n_segments > 1 ? a->seg_ptr : nullptr, a->n_segments, out_rows,
                               gn_blocks_for(out_rows), ws.partial, ws.stats, G(DIFUSCO_W_OUT_GN_W), G(DIFUSCO_W_OUT_GN_B),
@@ -450,7 +467,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                               a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st,
                               a->gn_phase, a->gn_sums))
 #undef PROF
-  return DIFUSCO_OK;
+  return finish();
 }
 
 int difusco_linear_rows(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t m,

@@ -715,6 +715,21 @@ hipError_t launch_gaussian_posterior(const float* pred, const float* xt, const f
   return hipGetLastError();
 }
 
+__global__ void count_nonfinite_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ count) {
+  unsigned bad = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    bad += !__builtin_isfinite(x[i]);
+  if (bad) atomicAdd(count, bad);
+}
+
+hipError_t launch_count_nonfinite(const float* x, long long n, unsigned* count, hipStream_t stream) {
+  if (n <= 0 || x == nullptr) return hipSuccess;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, count);
+  return hipGetLastError();
+}
+
 hipError_t launch_tile_absmax_tiled(const float* e, long long n_tiles, float* tile_max, hipStream_t stream) {
   if (n_tiles <= 0) return hipSuccess;
   hipLaunchKernelGGL(tile_absmax_tiled_kernel, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, stream, e, n_tiles, tile_max);

@@ -58,6 +58,8 @@ hipError_t linear_scalar_embed_split(const float* x, const int* perm, const floa
 
 // scale[r] = power-of-two operand scale of row r of x[m][k] (fp16 split path)
 hipError_t launch_row_pow2_scale(const float* x, long long m, int k, float* scale, hipStream_t stream);
+// *count += number of inf / nan values in x[0..n)  (DIFUSCO_FLAG_CHECK_FINITE)
+hipError_t launch_count_nonfinite(const float* x, long long n, unsigned* count, hipStream_t stream);
 // tile_max[t] = max |e| over the 32-edge tile t of a TILED [rows_padded, 256] buffer
 hipError_t launch_tile_absmax_tiled(const float* e, long long n_tiles, float* tile_max, hipStream_t stream);
 

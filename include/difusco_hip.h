@@ -31,7 +31,8 @@ enum {
   DIFUSCO_EINVAL = -1,      /* bad argument (shape, null pointer, unsupported hidden size ...) */
   DIFUSCO_EWORKSPACE = -2,  /* workspace too small */
   DIFUSCO_EHIP = -3,        /* a HIP runtime call failed */
-  DIFUSCO_EUNSUPPORTED = -4 /* e.g. aggregation other than "sum" (gnn_encoder.py:184-188) */
+  DIFUSCO_EUNSUPPORTED = -4, /* e.g. aggregation other than "sum" (gnn_encoder.py:184-188) */
+  DIFUSCO_ENONFINITE = -5    /* DIFUSCO_FLAG_CHECK_FINITE: the step produced inf / nan */
 };
 
 enum { DIFUSCO_TASK_TSP = 0, DIFUSCO_TASK_MIS = 1 };            /* edge features | node features only */
@@ -184,7 +185,12 @@ typedef struct difusco_step_args {
 
 enum {
   DIFUSCO_FLAG_NO_L0_FOLD = 1,   /* first layer: write e0 to memory and run the general kernel (no 2-row table fold) */
-  DIFUSCO_FLAG_NO_TAIL_FOLD = 2  /* last layer: general kernel + separate GroupNorm statistics pass over e */
+  DIFUSCO_FLAG_NO_TAIL_FOLD = 2, /* last layer: general kernel + separate GroupNorm statistics pass over e */
+  DIFUSCO_FLAG_CHECK_FINITE = 4  /* debugging aid: after the step, count the non-finite values of xt_out, of the head's GroupNorm
+                                    statistics (nan as soon as the final state holds an inf / nan) and of pred_out / prob_out
+                                    when given, synchronise the stream and return DIFUSCO_ENONFINITE if there are any.  The
+                                    arithmetic has no operand-range restriction (any finite fp32 weights / inputs), so inf / nan
+                                    can only come in with the inputs or from genuine fp32 overflow of the network itself. */
 };
 
 size_t difusco_workspace_bytes(int hidden, int n_layers, int n_nodes, int n_edges, int n_segments);

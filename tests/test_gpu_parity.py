@@ -1111,6 +1111,35 @@ def test_other_paths_at_adversarial_weight_scales(dev, variant, groups, exp):
     assert (prob.cpu().reshape(-1) - ref_prob.reshape(-1)).abs().max().item() < TOL
 
 
+def test_no_operand_range_limit_and_finite_check(dev):
+    """the residual stream e used to overflow the fp16 planes silently at |e| >= 65504.  With the per-tile
+    scale any finite value works: edge embedding x 2^22 (|e| ~ 10^6) still matches the oracle.  And DIFUSCO_FLAG_CHECK_FINITE
+    turns a genuinely non-finite step (an inf planted in a bias) into an error instead of silent garbage."""
+    from difusco_amd import TSPModel, _lib
+    H, Lyr = 256, 4
+    base = O.init_params(H, Lyr, 2, seed=79)
+    pts, ei = O.tsp_instance(60, 10, seed=4)
+    pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
+    g = torch.Generator().manual_seed(9)
+    xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
+    u = torch.rand(ei.shape[1], generator=g)
+    p = _scaled_params(base, ("edge_embed",), 2.0 ** 22, Lyr)
+    _, ref, _ = O.tsp_categorical_denoise_step(p, O.CategoricalTables(), pts, xt, 500, ei, 469, uniform=u, return_aux=True)
+    m = TSPModel(_args("categorical", 10, H=H, L=Lyr), p, device=dev, flags=_lib.FLAG_CHECK_FINITE)
+    _, out, _ = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([500]), dev, ei.to(dev), target_t=np.array([469]),
+                                           uniform=u, return_aux=True)
+    err = (out.cpu() - ref).abs().max().item()
+    print(f"edge embedding x 2^22 (|e| ~ 1e6): logits L_inf {err:.2e}")
+    assert torch.isfinite(out).all() and err < TOL
+    bad = {k: v.clone() for k, v in base.items()}
+    bad["per_layer_out.1.2.bias"][7] = float("inf")
+    mb = TSPModel(_args("categorical", 10, H=H, L=Lyr), bad, device=dev, flags=_lib.FLAG_CHECK_FINITE)
+    with pytest.raises(_lib.DifuscoHipError, match="non-finite"):
+        mb.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([500]), dev, ei.to(dev), target_t=np.array([469]), uniform=u)
+    mq = TSPModel(_args("categorical", 10, H=H, L=Lyr), bad, device=dev)          # without the flag: no check, no sync
+    mq.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([500]), dev, ei.to(dev), target_t=np.array([469]), uniform=u)
+
+
 @pytest.mark.parametrize("task", ["tsp", "mis"])
 def test_free_running_trajectory_fused_h256(dev, task):
     """test_free_running_trajectory on the DEFAULT path (H=256, fused kernel, fp16x3): GPU and oracle each feed their
