@@ -16,8 +16,8 @@
 //     half) of a 32x32x16 MFMA: the epilogued accumulators of GEMM 1 feed GEMM 2 straight from registers,
 //     no LDS round trip.  The weight planes are stored in that k order (weights.py: slab position order
 //     {0..3, 8..11, 4..7, 12..15}).
-//   * fp32 operands are split into two 16-bit planes (fp16: 22 significand bits, or bf16) and multiplied
-//     with 3 MFMA products (hi*hi, hi*lo, lo*hi), accumulated in fp32 (see linear_split.hip).
+//   * fp32 operands are split into two 16-bit planes (fp16 planes of power-of-two-scaled operands - see `scales` at the
+//     kernel - or bf16) and multiplied with 3 MFMA products (hi*hi, hi*lo, lo*hi), accumulated in fp32 (see linear_split.hip).
 // A wave owns a 32-edge tile end to end; a workgroup is 4 waves (two workgroups per CU, whose phases drift
 // apart so that one's MFMA phases overlap the other's VALU / address-heavy epilogue) - see fused::Geo.
 // Weights stream through LDS in stages of 256 rows of 32 bytes x 2 planes ([256 rows][16 k] slabs for GEMM 1,
@@ -26,6 +26,9 @@
 // 16-lane group of ds_read_b128 hits 16 distinct 16-byte bank slots without padding (the swizzle is applied to the
 // per-lane source address of the DMA, whose LDS side is lane-linear).  GEMM 2 runs in four quarters of 64 output features (32
 // accumulator registers) so that act planes (128) + accumulators + staging fit 256 VGPRs (2 waves/SIMD).
+//
+// Neighbour-table rows A h[j], V h[j] reach the lanes by FULL-LINE gathers: LDS-DMA into the wave's idle share of a weight stage
+// buffer, conflict-free ds_read_b128 back (OPT bit 14 at the gather phase); B h[i] by plain buffer loads.
 //
 // Neighbour sum.  The gated messages m of a tile are transposed through a wave-private LDS scratch
 // (64 features per round) and summed per centre-node segment by lanes = features.  A segment that is
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   if constexpr ((OPT & 512) != 0) __builtin_amdgcn_s_setprio(3);
   // ================================ epilogue 1 =======================================================
   // quad (nb, g): features fb = 32 nb + 8 g + 4 hh + 0..3 of edge s, accumulator registers 4g..4g+3.
-  // Neighbour-table rows are gathered one batch (= 2 quads) ahead of their use.
+  // Neighbour-table rows: full-line gathers through LDS (OPT bit 14, production) or register gathers one batch (= 2 quads) ahead.
   // OPT bit 6: the four LayerNorm reductions (sum, centred sum of squares, twice) run as FOUR interleaved partial sums per
   // lane instead of one 128-term serial chain each; same terms, different summation order (fp32 rounding only)
   constexpr bool kPart = (OPT & 64) != 0;
