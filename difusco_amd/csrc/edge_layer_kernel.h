@@ -597,6 +597,95 @@ _Pragma("unroll")                                                               
   // request cannot be pending when the count is reached - whatever the neighbour-sum stores (same counter) do.
   constexpr bool kFL2 = kFL && (OPT & 32768) != 0;
   static_assert(!kFL2 || !kPersist, "bits 12 and 15 are not combined");
+  // OPT bit 16 (with bit 14, experiment): the same full-line access pattern, but through REGISTERS - four buffer_load_dwordx4 per
+  // unit land in staging registers (lane L: row 8 p + L / 8, chunk (L % 8) ^ swz(row)) and are written to the unit lane-linearly
+  // (ds_write_b128), then read back as before.  No LDS-DMA issue cost, no manual waits (the compiler tracks the staging registers;
+  // LDS operations of one wave execute in order), the next block's loads are in flight one whole block ahead.
+  constexpr bool kFL3 = kFL && (OPT & 65536) != 0;
+  if constexpr (kFL3) {
+    const int rsel = lane >> 3, cc = lane & 7;
+    auto swz = [](int r) { return ((r >> 1) & 3) | (((r >> 4) & 1) << 2); };
+    int src_off[4];
+#pragma unroll
+    for (int p4 = 0; p4 < 4; ++p4) {
+      const int r = 8 * p4 + rsel;
+      const int jr = __shfl(j, r, 64);
+      src_off[p4] = jr * (4 * H * 4) + ((cc ^ swz(r)) * 16);
+    }
+    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(node4), 0, 0xffffffff, 0x00020000);
+    unsigned char* const ua0 = reinterpret_cast<unsigned char*>(wbuf + BUF + (PP * wave) * 512);           // rows 0-15
+    unsigned char* const ua1 = reinterpret_cast<unsigned char*>(wbuf + BUF + PLANE + (PP * wave) * 512);   // rows 16-31
+    const unsigned char* const rd_a = ((l31 & 16) ? ua1 : ua0) + (l31 & 15) * 128;
+    int rd_pos[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rd_pos[g] = ((2 * g + hh) ^ swz(l31)) * 16;
+    const int b_voff = i_node * (4 * H * 4) + hh * 16;
+    v4f stg_a[4], stg_v[4], bh_q[4];
+#define FUSED_FL3_LOAD(dst, table, nb_)                                                                                    \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4)                                                                      \
+      dst[p4] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_n, src_off[p4], (table) * H * 4 + (nb_) * 128, 0)); \
+  }
+#define FUSED_FL3_TRANSPOSE(src, dst)                                                                                      \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4)                                                                      \
+      *reinterpret_cast<v4f*>(((p4 >> 1) ? ua1 : ua0) + (p4 & 1) * 1024 + lane * 16) = src[p4];                           \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const v4f*>(rd_a + rd_pos[g]);                \
+  }
+#define FUSED_FL3_B(nb_)                                                                                                   \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                                         \
+      bh_q[g] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_n, b_voff, (3 * H + 32 * (nb_) + 8 * g) * 4, 0)); \
+  }
+    FUSED_FL3_B(0)
+    FUSED_FL3_LOAD(stg_a, 2, 0)
+    if constexpr (TAIL != 1) { FUSED_FL3_LOAD(stg_v, 1, 0) }
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const int nq = nb & 1;
+      v4f ah_q[4], vh_q[4];
+      v2f sg_q[4][2];
+      FUSED_FL3_TRANSPOSE(stg_a, ah_q)
+      if (nb + 1 < 8) { FUSED_FL3_LOAD(stg_a, 2, nb + 1) }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fb = 32 * nb + 8 * g + 4 * hh;
+        const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int r = 4 * g + 2 * h2;
+          v2f ce;
+          if constexpr (T::kScaled && !L0) ce = DIFUSCO_PAIR(acc1[nb], r) * v2f{inv1, inv1} + DIFUSCO_PAIR(bc, 2 * h2);
+          else ce = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(bc, 2 * h2);
+          const v2f ev = (DIFUSCO_PAIR(ah_q[g], 2 * h2) + DIFUSCO_PAIR(bh_q[g], 2 * h2)) + ce;
+          acc1[nb][r] = ev[0];
+          acc1[nb][r + 1] = ev[1];
+          s1k[h2] += ev;
+          if constexpr (TAIL != 1) sg_q[g][h2] = fast_sigmoid2(ev);
+        }
+      }
+      if (nb + 1 < 8) { FUSED_FL3_B(nb + 1) }
+      if constexpr (TAIL != 1) {
+        FUSED_FL3_TRANSPOSE(stg_v, vh_q)
+        if (nb + 1 < 8) { FUSED_FL3_LOAD(stg_v, 1, nb + 1) }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          v4f m;
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const v2f sg = sg_q[g][h2] * DIFUSCO_PAIR(vh_q[g], 2 * h2);
+            m[2 * h2] = valid ? sg[0] : 0.0f;
+            m[2 * h2 + 1] = valid ? sg[1] : 0.0f;
+          }
+          *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
+        }
+        if (nq == 1) { FUSED_AGG_ROUND(nb >> 1) }
+      }
+    }
+#undef FUSED_FL3_LOAD
+#undef FUSED_FL3_TRANSPOSE
+#undef FUSED_FL3_B
+  } else
   if constexpr (kFL) {
     const int rsel = lane >> 3, cc = lane & 7;
     auto swz = [](int r) { return ((r >> 1) & 3) | (((r >> 4) & 1) << 2); };
@@ -1190,6 +1279,7 @@ hipError_t launch_fused_opt(A... args) {
     case 3955: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 3955>(args...);    // (A/B: round 2's production: register gathers)
     case 53107: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 53107>(args...);  // (A/B: ... + two units, counted waits)
     case 19827: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 19827>(args...);  // (A/B: production without the raised issue priority)
+    case 85875: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 85875>(args...);  // (A/B: full-line gathers through staging registers)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 #endif
