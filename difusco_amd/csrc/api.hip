@@ -485,8 +485,8 @@ int difusco_linear_rows_split(const float* x, const void* planes, int precision,
   if (!x || !planes || !y) return fail(DIFUSCO_EINVAL, "null pointer");
   if (precision < DIFUSCO_PREC_BF16X3 || precision > DIFUSCO_PREC_FP16X3)
     return fail(DIFUSCO_EINVAL, "precision must be BF16X3, BF16X6 or FP16X3");
-  if (k != n_out || !(k == 64 || k == 128 || k == 256) || ldy < n_out)
-    return fail(DIFUSCO_EINVAL, "split path needs k == n_out in {64,128,256}, ldy >= n_out");
+  if (!(k == 64 || k == 128 || k == 256) || (n_out != k && !(k == 256 && n_out > 0 && n_out % 256 == 0)) || ldy < n_out)
+    return fail(DIFUSCO_EINVAL, "split path needs k in {64,128,256}, n_out == k (or a multiple of 256 for k = 256), ldy >= n_out");
   const unsigned short* pl = reinterpret_cast<const unsigned short*>(planes);
   difusco::SplitScale sc;
   if (precision == DIFUSCO_PREC_FP16X3) {
@@ -582,7 +582,8 @@ int difusco_debug_set(int key, int value) {
   if (key == 6) { difusco::g_fused_lds_pad = value; return DIFUSCO_OK; }
   if (key == 9) { difusco::g_fused_start_delay = value; return DIFUSCO_OK; }
   if (key == 7) { difusco::g_fused_opt = value; return DIFUSCO_OK; }
-  if (key == 8 && (value == 1 || value == 4)) { difusco::g_node_linear_depth = value; return DIFUSCO_OK; }
+  if (key == 10 && value >= 0 && value <= 31) { difusco::g_node_linear_ablate = value; return DIFUSCO_OK; }
+  if (key == 8 && (value == 0 || value == 1 || value == 4)) { difusco::g_node_linear_depth = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }
 #endif  // DIFUSCO_PROFILING

@@ -51,6 +51,11 @@ hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long
                              const float* bias, const float* residual, float* y, long long m, int k, int n_out,
                              long long ldy, hipStream_t stream, int tiled_out = 0, SplitScale sc = SplitScale());
 
+// the same product for k = 256, n_out % 128 == 0, modes 1 / 3, row-major y with ldy = n_out, no residual (node_linear.hip):
+// rows register resident, weight planes streamed through LDS.  linear_rows_split routes the node-row shape here.
+hipError_t node_linear(const float* x, const float* row_scale, long long m, const unsigned short* planes, long long plane_stride,
+                       int mode, int n_out, const float* w_inv, const float* bias, float* y, hipStream_t stream);
+
 // Y = ScalarEmbeddingSine(x[perm]) W^T + b, the [m,256] embedding generated inside the kernel (split planes, modes 1 / 3)
 hipError_t linear_scalar_embed_split(const float* x, const int* perm, const float* dimt, const unsigned short* wp,
                                      long long plane_stride, int mode, const float* bias, float* y, long long m,
@@ -87,6 +92,7 @@ extern int g_fused_lds_pad;
 extern int g_fused_start_delay;
 extern int g_fused_opt;
 extern int g_node_linear_depth;
+extern int g_node_linear_ablate;
 extern unsigned long long* g_fused_dbg;
 #endif
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,

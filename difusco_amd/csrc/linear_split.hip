@@ -268,10 +268,12 @@ static hipError_t launch_split(const float* x, const unsigned short* wp, long lo
 }
 
 #ifdef DIFUSCO_PROFILING
-int g_node_linear_depth = 4;     // A/B knob of the profiling library (difusco_debug_set key 8: 1 or 4 k steps of lookahead)
+// A/B knob of the profiling library (difusco_debug_set key 8): 0 = node_linear.hip (production), 4 / 1 = this file's kernel with
+// 4 / 1 k steps of lookahead (rounds 2 / 1)
+int g_node_linear_depth = 0;
 #define NODE_LINEAR_DEPTH g_node_linear_depth
 #else
-#define NODE_LINEAR_DEPTH 4
+#define NODE_LINEAR_DEPTH 0
 #endif
 
 // wp: first plane of the chosen element type, plane p at wp + p*plane_stride, each [K/16][n_out][16]
@@ -295,7 +297,11 @@ hipError_t linear_rows_split(const float* x, const unsigned short* wp, long long
   // (node linears 0.49 -> 0.42 ms/step at 8000 rows x 1024 outputs; 64-column blocks measured slower: 0.475;
   // round 2: two / four k slabs per LDS step - half / a quarter of the barriers - measured 0.433 / 0.546 vs 0.431 ms/step)
   if (k == 256 && !tiled_out && n_out % 128 == 0 && ((m + 127) / 128) * (n_out / 256) < 512) {
-    if (NODE_LINEAR_DEPTH == 4) {      // (profiling library: key 8 = 1 restores the one-step lookahead for A/B)
+    // the node-row shape (wide output, few row blocks): rows register resident, weights streamed through LDS (node_linear.hip)
+    if (NODE_LINEAR_DEPTH == 0 && (mode == 1 || mode == 3) && residual == nullptr && ldy == n_out && sc.x_scale == 1.0f &&
+        (mode == 1 || (sc.row_scale != nullptr && sc.w_inv != nullptr)))
+      return node_linear(x, sc.row_scale, m, wp, plane_stride, mode, n_out, sc.w_inv, bias, y, stream);
+    if (NODE_LINEAR_DEPTH != 1) {      // (profiling library: key 8 = 1 restores the one-step lookahead for A/B)
       if (mode == 1) return launch_split<256, 128, 2, Bf16, false, 4>(DIFUSCO_SPLIT_ARGS);
       if (mode == 3) return launch_split<256, 128, 2, Fp16, false, 4>(DIFUSCO_SPLIT_ARGS);
     }

@@ -206,7 +206,8 @@ int difusco_linear_rows(const float* x, const float* w, const float* bias, const
                         float* y, int64_t m, int k, int n_out, int64_t ldy, void* stream);
 /* Same contract on the split-precision path: `planes` = the five 16-bit planes of W[n_out,k] in the
  * *_PLANES layout above (planes + inverse scales); precision = DIFUSCO_PREC_BF16X3 | _BF16X6 | _FP16X3.
- * k == n_out in {64,128,256}.  row_scale_scratch (device, m floats, or NULL): with FP16X3 the rows of x are scaled
+ * k == n_out in {64,128,256}, or k = 256 with n_out a multiple of 256 (the node-row shape, n_out = 1024: a row-major y with
+ * ldy == n_out and no residual then takes the register-resident kernel of node_linear.hip).  row_scale_scratch (device, m floats, or NULL): with FP16X3 the rows of x are scaled
  * individually by a power of two computed in an extra pass (any finite |x|); NULL skips that pass and then needs
  * 2^-3 <= |x| < 65504 for the full 22 bits. */
 int difusco_linear_rows_split(const float* x, const void* planes, int precision, const float* bias,

@@ -132,6 +132,31 @@ def test_linear_rows_split_any_operand_scale(dev, L, prec, tol, wexp, xexp):
     assert err < tol, err
 
 
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16x6", 6e-7), ("fp16x3", 1.5e-6)])
+@pytest.mark.parametrize("m", [1, 127, 128, 129, 1000, 8000])
+def test_node_linear_shape(dev, L, prec, tol, m):
+    """The node-row shape of a layer (gnn_encoder.py:94-103: U | V | A | B as one [1024, 256] matrix, per-row weight scales)
+    through the C ABI: bf16x3 / fp16x3 take node_linear.hip (rows register resident, weights streamed through LDS), bf16x6 the
+    general kernel.  Error per row relative to the row's max |Y| against fp64; rows of x at 2^+-6 different magnitudes."""
+    from difusco_amd import weights
+    g = torch.Generator().manual_seed(m)
+    k, n_out = 256, 1024
+    x = torch.randn(m, k, generator=g) * (2.0 ** torch.randint(-6, 7, (m, 1), generator=g).float())
+    w = torch.randn(n_out, k, generator=g) / 16 * (2.0 ** torch.randint(-5, 3, (n_out, 1), generator=g).float())
+    b = torch.randn(n_out, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    planes = weights.split_planes(w, per_row=True).to(dev)
+    xd, bd, rs = x.to(dev), b.to(dev), torch.empty(m, device=dev)
+    y = torch.full((m + 1, n_out), float("nan"), device=dev)
+    L.check(L.lib().difusco_linear_rows_split(_p(xd), _p(planes), L.PRECISIONS[prec], _p(bd), None, _p(y), m, k, n_out, n_out, _p(rs), _stream()))
+    torch.cuda.synchronize()
+    assert torch.isnan(y[m]).all()                     # nothing written past the last row
+    scale = (x.double().abs() @ w.double().abs().t()).amax(dim=1, keepdim=True) + b.double().abs().max()
+    err = ((y[:m].cpu().double() - ref).abs() / scale).max().item()
+    print(f"{prec} m={m}: rel err {err:.2e}")
+    assert err < tol, err
+
+
 def test_linear_rows_rejects_bad_shapes(L, dev):
     x = torch.zeros(4, 100, device=dev)
     assert L.lib().difusco_linear_rows(_p(x), _p(x), None, None, _p(x), 4, 100, 64, 64, _stream()) == -1
