@@ -1,14 +1,14 @@
 // Node-row linear of a DIFUSCO layer for gfx950: node4 = h W4^T + b with W4 = [U | V | A | B] (gnn_encoder.py:52-55,94-103), the
 // [N, 256] x [256, 1024] product that feeds the fused edge kernel's neighbour tables, on the split-precision matrix-core path.
 //
-// Same dataflow as GEMM 1 of the fused edge kernel (edge_layer_kernel.h): the DATA rows are the register-resident B operand, the
+// Same dataflow as GEMM 1 of the fused edge kernel (edge_layer_kernel.h): the DATA rows are a register-resident MFMA operand, the
 // WEIGHTS stream through LDS.
-//   * a wave owns 32 node rows: their 256 features are loaded once (16 slabs x two float4 per lane), scaled by the row's power-of-two
-//     operand scale and split into two 16-bit planes in registers (128 VGPRs) - no LDS staging of X, no per-k-step barrier pair;
+//   * a wave owns 32 node rows: their 256 features are loaded once as full lines, transposed through LDS to lane = row, scaled by
+//     the row's power-of-two operand scale and split into two 16-bit planes in registers (128 VGPRs) - no per-k-step barrier pair;
 //   * a workgroup (4 waves, 128 rows) computes 128 output columns: the weight planes of those columns stream through LDS in 8
 //     stages of 2 slabs x [128 rows][16 k] x 2 planes (16 KB) by LDS-DMA, three buffers, requests two stages ahead of the MFMAs
 //     (counted vmcnt waits), one barrier per stage; rows XOR-swizzled like the fused kernel's stages (conflict-free ds_read_b128);
-//   * D[f][row] accumulators (transposed MFMA): a lane owns 4 consecutive output features of its row per quad - 16-byte stores.
+//   * D[row][f] accumulators: a lane owns one output feature of 16 rows per block, a store instruction writes 2 rows x 128 B.
 // The general row-linear (linear_split.hip) stages both operands through LDS with two barriers per 16-k step and re-splits X in every
 // one of its 8 column-block workgroups; at 8,000 rows it spent half its wave cycles in s_waitcnt / s_barrier (profiles/r03).
 #include "edge_layer_common.h"
@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256, 2) void node_linear_kernel(const float* __rest
       }
       // smallest terms first per accumulator; the four accumulator chains alternate
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) acc[nb] = T::mfma(fl[nb], xh[ks], acc[nb]);
+      for (int nb = 0; nb < 4; ++nb) acc[nb] = T::mfma(xh[ks], fl[nb], acc[nb]);
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) acc[nb] = T::mfma(fh[nb], xl[ks], acc[nb]);
+      for (int nb = 0; nb < 4; ++nb) acc[nb] = T::mfma(xl[ks], fh[nb], acc[nb]);
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) acc[nb] = T::mfma(fh[nb], xh[ks], acc[nb]);
+      for (int nb = 0; nb < 4; ++nb) acc[nb] = T::mfma(xh[ks], fh[nb], acc[nb]);
     }
     if (t + 1 < NSTAGE) {      // stage t + 1 must have landed; stage t + 2 (just requested) may stay in flight
       if (t + 2 < NSTAGE) NODELIN_SYNC(4);
@@ -183,27 +183,36 @@ __global__ __launch_bounds__(256, 2) void node_linear_kernel(const float* __rest
     for (int ks = 0; ks < NSLAB; ++ks) acc[ks & 3][ks] += (float)xh[ks][0] + (float)xl[ks][1] + (float)xh[ks][7] + (float)xl[ks][4];
   }
   // (one 32-column block at a time over all of k, its stores issued inside the stage loop, measured 1 us SLOWER than storing
-  // everything here: the 32.8 MB of node4 take 7 - 8 us to drain whenever they are issued - scripts/bench_node_linear.py)
-  if (row_raw < M && (!(ABL & 1) || sc == 12345.678f)) {
-    float rinv = 1.0f;
-    if constexpr (T::kScaled) rinv = __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, sc));   // 1 / 2^k, exact
-    // all inverse scales / biases first, then the 16 stores back to back: a load issued after a store is waited for through the
-    // same counter (vmcnt), i.e. together with the store's acknowledgement (same box: 26.7 -> 25.9 us per call)
-    v4f wi[16], bi[16];
+  // everything here - scripts/bench_node_linear.py)
+  // D[row][feature] (rows = the A operand): lane = feature f0 + 32 nb + l31, register r = row 8 (r >> 2) + 4 hh + (r & 3) of the
+  // wave's 32, so one store instruction writes 2 rows x 128 B - whole lines.  (With D[feature][row], 16-byte stores of 32 rows x 32 B
+  // per instruction, the write counter showed 47.6 MB per launch for the 32.8 MB of node4 and the kernel took 3.7 us longer.)
+  // Scales and biases are loaded before the first store: a load issued after a store is waited for through the same counter
+  // (vmcnt), i.e. together with the store's acknowledgement.
+  const long long rbase = (long long)rb_i * RB + wave * 32;
+  if (rbase < M && (!(ABL & 1) || sc == 12345.678f)) {
+    float wv[4], bv[4], rs[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int f = f0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * hh;
-      if constexpr (T::kScaled) wi[q] = *reinterpret_cast<const v4f*>(w_inv + f) * rinv;
-      bi[q] = bias != nullptr ? *reinterpret_cast<const v4f*>(bias + f) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int nb = 0; nb < 4; ++nb) {
+      wv[nb] = T::kScaled ? w_inv[f0 + nb * 32 + l31] : 1.0f;
+      bv[nb] = bias != nullptr ? bias[f0 + nb * 32 + l31] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long rr = rbase + 8 * (r >> 2) + 4 * hh + (r & 3);
+      rs[r] = 1.0f;     // 1 / 2^k of the row, exact
+      if constexpr (T::kScaled) rs[r] = __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(unsigned, row_scale[rr < M ? rr : M - 1]));
     }
     asm volatile("" ::: "memory");
+    float* yb = Y + (rbase + 4 * hh) * n_out + f0 + l31;
+    const bool full = rbase + 32 <= M;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int nb = q >> 2, g = q & 3, f = f0 + nb * 32 + 8 * g + 4 * hh;
-      v4f v = {acc[nb][4 * g + 0], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
-      if constexpr (T::kScaled) v = v * wi[q];
-      v += bi[q];
-      *reinterpret_cast<v4f*>(Y + row * n_out + f) = v;
+    for (int r = 0; r < 16; ++r) {
+      const int m = 8 * (r >> 2) + (r & 3);
+      if (full || rbase + 4 * hh + m < M) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) yb[(long long)m * n_out + nb * 32] = acc[nb][r] * (wv[nb] * rs[r]) + bv[nb];
+      }
     }
   }
 }

@@ -33,15 +33,16 @@ def run(reps):
         L.check(lib.difusco_linear_rows_split(p(x), p(planes), L.PRECISIONS["fp16x3"], p(b), None, p(y), m, k, n_out, n_out, p(rs), st))
 
 
-out = {"m": m, "k": k, "n_out": n_out, "note": "us per call = row_pow2_scale pass (~5 us at m = 8000) + the linear kernel; two passes over the cases", "cases": {}}
+out = {"m": m, "k": k, "n_out": n_out, "note": "us per call = row_pow2_scale pass (~5 us at m = 8000) + the linear kernel; four passes over the cases in rotated order", "cases": {}}
 CASES = (("node_linear.hip", ((8, 0), (10, 0))), ("general split kernel, lookahead 4", ((8, 4), (10, 0))),
          ("variant: direct lane = row loads of x", ((8, 0), (10, 16))),
          ("ablation: no stores", ((8, 0), (10, 1))), ("ablation: no x loads", ((8, 0), (10, 2))),
          ("ablation: no weight stream / mfma", ((8, 0), (10, 4))), ("ablation: no stores, no x loads", ((8, 0), (10, 3))),
          ("ablation: no stores, no weights", ((8, 0), (10, 5))), ("ablation: launch only", ((8, 0), (10, 7))))
 run(300)      # clocks up
-for _ in range(2):
-    for name, sets in CASES:
+for rot in range(4):          # four passes, the order rotated: the position in the sequence moves a case by up to 1.5 us
+    order = CASES[rot * 3 % len(CASES):] + CASES[:rot * 3 % len(CASES)]
+    for name, sets in order:
         for key, val in sets:
             assert lib.difusco_debug_set(key, val) >= 0
         run(20)
