@@ -9,8 +9,12 @@
 // (difusco/models/gnn_encoder.py:104 `C`, :344 `per_layer_out[2]`, :395 `edge_embed`) become HBM-bound.
 //
 // A third mode decomposes into TWO fp16 planes (11+11 significand bits, 3 products): fp32-class accuracy
-// at half the matrix-core work of the 6-product bf16 mode, valid while |x| < 65504 (the operands here are
-// LayerNorm-bounded activations, the residual stream and weights).
+// at half the matrix-core work of the 6-product bf16 mode.  fp16 has 5 exponent bits, so both operands are
+// first scaled by exact powers of two into [2^14, 2^15) at their maximum (weights per matrix / per row on the
+// host, rows of x by SplitScale::row_scale) and the product of the inverse scales is applied where
+// the bias is added - any finite fp32 operand keeps its 22 bits.
+// The node-row shape of a layer ([N,256] x [256,1024]) has its own kernel (node_linear.hip); this one serves the
+// E-row linears of the unfused path and the remaining shapes.
 //
 // Inside every 16-wide k slab the two middle groups of 4 are swapped (slab position j holds
 // k = {0..3, 8..11, 4..7, 12..15}[j]) - the order in which a 32x32 MFMA accumulator hands 8 of its
