@@ -9,8 +9,10 @@
 //     stages of 2 slabs x [128 rows][16 k] x 2 planes (16 KB) by LDS-DMA, three buffers, requests two stages ahead of the MFMAs
 //     (counted vmcnt waits), one barrier per stage; rows XOR-swizzled like the fused kernel's stages (conflict-free ds_read_b128);
 //   * D[row][f] accumulators: a lane owns one output feature of 16 rows per block, a store instruction writes 2 rows x 128 B.
-// The general row-linear (linear_split.hip) stages both operands through LDS with two barriers per 16-k step and re-splits X in every
-// one of its 8 column-block workgroups; at 8,000 rows it spent half its wave cycles in s_waitcnt / s_barrier (profiles/r03).
+// The general row-linear (linear_split.hip) stages both operands through LDS with two barriers per 16-k step.  At 8,000 rows the
+// whole product is ONE round of 504 workgroups, so the load, MFMA and store phases of all CUs coincide and add up (timing ablations:
+// scripts/bench_node_linear.py, profiles/r03/node_linear_microbench.json); what shortened it was the full-line X loads and the
+// full-line stores, not the leaner stage loop: rocprofv3 29.3 -> 22.9 us per launch.
 #include "edge_layer_common.h"
 
 namespace difusco {
