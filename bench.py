@@ -42,7 +42,7 @@ def pmc_traffic_bytes(kernel_name, workload, n_edges, variant):
     profiles/r03/pmc_traffic.json (this round's kernel), then profiles/r02/pmc_traffic.json, are keyed by
     "<workload>:<edges on rank 0>:<variant>", i.e. by the exact run the counters were collected on; a run with no profile
     of its own reports None (never another workload's bytes)."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         try:
             table = json.load(open(path))
@@ -57,6 +57,23 @@ def pmc_traffic_bytes(kernel_name, workload, n_edges, variant):
                         "write_bytes": val["write_bytes"],
                         "source": f"profiles/{rnd}/pmc_traffic.json[{workload}:{n_edges}:{variant}] (rocprofv3 --pmc)"}
     return None
+
+
+def pmc_pipe_busy(workload, n_edges, variant, avg_launch_s, n_simd=1024, clock_hz=2.4e9):
+    """Matrix-pipe occupancy of the dominant kernel: SQ_VALU_MFMA_BUSY_CYCLES per launch (rocprofv3 --pmc pass of the same
+    run key, profiles/r04/pmc_sq.json; averaged over the launches of a step) / (SIMDs x live average launch time x the
+    2.4 GHz the peak is quoted at).  None when that run was never profiled."""
+    path = os.path.join(ROOT, "profiles", "r04", "pmc_sq.json")
+    try:
+        entry = json.load(open(path)).get(f"{workload}:{n_edges}:{variant}")
+    except (OSError, ValueError):
+        entry = None
+    if not entry or "SQ_VALU_MFMA_BUSY_CYCLES" not in entry:
+        return None
+    busy = float(entry["SQ_VALU_MFMA_BUSY_CYCLES"])
+    return {"value": busy / (n_simd * avg_launch_s * clock_hz), "mfma_busy_cycles_per_launch": busy,
+            "source": f"profiles/r04/pmc_sq.json[{workload}:{n_edges}:{variant}] (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES) / "
+                      f"({n_simd} SIMDs x live avg launch x 2.4 GHz)"}
 
 
 def oracle_threads():
@@ -202,6 +219,12 @@ def main():
                          "(bf16x6 keeps all 24 significand bits: fp32-class accuracy)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` sub-record (the other north_star sizes: "
                     "tsp500, tsp10000, mis - a few timed steps each with their own roofline, cpu_baseline and parity_linf)")
+    ap.add_argument("--repeats", type=int, default=3, help="repetitions of the timed K-step loop (each between its own fences); the "
+                    "headline is the median repetition, all of them are listed under `repeats`")
+    ap.add_argument("--backend", default="ctypes", choices=["ctypes", "torch"], help="host binding of the C ABI: ctypes, or the "
+                    "PyTorch custom ops torch.ops.difusco.* (csrc/torch_ops.cpp)")
+    ap.add_argument("--no-prepare", action="store_true", help="A/B: recompute the step-invariant part of a TSP step (node "
+                    "embedding, layer-0 node linear, time-bias rows) in every step instead of once per (graph, schedule)")
     ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of each `workloads` entry (2 warm-up steps)")
     args = ap.parse_args()
 

@@ -7,7 +7,7 @@ from .build import LIB_PATH, PROF_LIB_PATH
 
 FLAG_NO_L0_FOLD, FLAG_NO_TAIL_FOLD, FLAG_CHECK_FINITE = 1, 2, 4      # difusco_step_args.flags
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
@@ -48,6 +48,7 @@ class StepArgs(ctypes.Structure):
         ("precision", ctypes.c_int32), ("no_fusion", ctypes.c_int32),
         ("row", ctypes.c_void_p),
         ("gn_phase", ctypes.c_int32), ("flags", ctypes.c_int32), ("gn_sums", ctypes.c_void_p),
+        ("prepared", ctypes.c_void_p), ("tbias", ctypes.c_void_p),      # optional prepared state (ABI 9)
     ]
 
 
@@ -80,6 +81,10 @@ def lib():
     L.difusco_workspace_bytes.restype = ctypes.c_size_t
     L.difusco_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.difusco_denoise_step.argtypes = [ctypes.POINTER(StepArgs)]
+    L.difusco_prepared_bytes.restype = ctypes.c_size_t
+    L.difusco_prepared_bytes.argtypes = [i32, i32]
+    L.difusco_prepare.argtypes = [ctypes.POINTER(StepArgs), vp, ctypes.c_size_t]
+    L.difusco_time_bias_rows.argtypes = [i32, i32, i32, f32p, ctypes.POINTER(ctypes.c_float), i32, f32p, vp]
     L.difusco_linear_rows.argtypes = [f32p, f32p, f32p, f32p, f32p, i64, i32, i32, i64, vp]
     L.difusco_linear_rows_split.argtypes = [f32p, vp, i32, f32p, f32p, f32p, i64, i32, i32, i64, f32p, vp]
     L.difusco_fused_scratch_bytes.restype = ctypes.c_size_t
@@ -115,8 +120,14 @@ def lib():
                 raise DifuscoHipError(f"difusco_debug_set({kv}) failed: {L.difusco_last_error().decode()}")
     if L.difusco_abi_version() != ABI_VERSION:
         raise DifuscoHipError(f"ABI version mismatch: library {L.difusco_abi_version()} != binding {ABI_VERSION}")
+    L._difusco_path = path
     _lib = L
     return L
+
+
+def loaded_path() -> str:
+    """Path of the shared library behind ``lib()`` (production, profiling build or DIFUSCO_HIP_LIBRARY)."""
+    return lib()._difusco_path
 
 
 def check(code: int):

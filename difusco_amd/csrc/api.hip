@@ -130,6 +130,26 @@ Workspace carve(void* base, int H, int L, int64_t N, int64_t E, int S, int nblk)
 }
 
 
+// Prepared state of a TSP call shape (difusco_step_args.prepared): what a step computes from (weights, points) alone.
+struct Prepared {
+  float *h0, *node4_0, *table;      // [N,H], [N,4H], [4,H]
+  size_t bytes;
+};
+Prepared carve_prepared(void* base, int H, int64_t N) {
+  Prepared p;
+  size_t cur = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = cur;
+    cur = (cur + bytes + 255) / 256 * 256;
+    return base ? (float*)((char*)base + at) : (float*)nullptr;
+  };
+  p.h0 = take(sizeof(float) * N * H);
+  p.node4_0 = take(sizeof(float) * N * 4 * H);
+  p.table = take(sizeof(float) * 4 * H);
+  p.bytes = cur;
+  return p;
+}
+
 // ---- optional in-library profiler: HIP events around every kernel launch, per category ----------
 // (bench.py needs the average duration of the dominant kernel measured on the launch stream inside
 // the timed region; the launches happen inside difusco_denoise_step, so the brackets live here.)
@@ -237,7 +257,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
   if (N <= 0 || E < 0) return fail(DIFUSCO_EINVAL, "n_nodes must be > 0, n_edges >= 0");
   if (!a->weights || !a->rowptr || (E > 0 && !a->col) || !a->xt || !a->xt_out || !a->workspace)
     return fail(DIFUSCO_EINVAL, "null device pointer (weights/rowptr/col/xt/xt_out/workspace)");
-  if (a->task == DIFUSCO_TASK_TSP && !a->points) return fail(DIFUSCO_EINVAL, "TSP needs points");
+  if (a->task == DIFUSCO_TASK_TSP && !a->points && !a->prepared) return fail(DIFUSCO_EINVAL, "TSP needs points");
   if (a->task == DIFUSCO_TASK_TSP && E == 0) return fail(DIFUSCO_EINVAL, "TSP needs edges");
   if (a->n_segments < 1 || (a->n_segments > 1 && !a->seg_ptr))
     return fail(DIFUSCO_EINVAL, "n_segments >= 1, seg_ptr required when > 1");
@@ -294,8 +314,9 @@ int difusco_denoise_step(const difusco_step_args* a) {
   const bool fused = H == 256 && !a->no_fusion && E > 0 && a->n_segments == 1 &&
                      (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
   if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
-  if (fused && N >= (1 << 20))      // the full-line neighbour-table gathers address node rows by 32-bit byte offsets (4 KB per node)
-    return fail(DIFUSCO_EUNSUPPORTED, "fused path: n_nodes must be < 2^20 per call (got %lld); set no_fusion", (long long)N);
+  // the full-line neighbour-table gathers address node rows by 32-bit byte offsets (4 KB per node): calls with 2^20 nodes or
+  // more take the register-gather instantiation of the same kernel (64-bit addresses, bit-identical results, ~3 % slower)
+  const int reg_gather = N >= (1 << 20) ? 1 : 0;
   const int64_t E_pad = (E + 255) / 256 * 256;
   // first layer: when the edge input is a table lookup (categorical TSP: embedding of the bit; MIS: zeros) the fused
   // kernel takes it from the table and the pass that would write e0 to HBM is skipped
@@ -312,10 +333,17 @@ int difusco_denoise_step(const difusco_step_args* a) {
                        (tsp ? a->xt_is_binary != 0 : true);
   const bool f16 = a->precision == DIFUSCO_PREC_FP16X3;
   const int64_t n_tiles_pad = E_pad / 32;
+  // prepared state (TSP, fused path only; anything else recomputes - the stateless step is always correct)
+  const bool use_prep = a->prepared != nullptr && fused && tsp && !ablating;
+  const Prepared prep = carve_prepared(const_cast<void*>(a->prepared), H, N);
+  const float* table = use_prep ? prep.table : ws.table;      // two-row edge-input table (+ C of layer 0 applied to it)
+  if (tsp && !a->points && !use_prep && !head_only)
+    return fail(DIFUSCO_EINVAL, "TSP needs points (only a fused-path step with prepared state runs without them)");
 
   // per-layer time bias rows: time_layer_l(time_embed(timestep_embedding(t)))   [L,H]
-  if (!head_only)
-  PROF(PROF_EMBED, launch_time_bias(a->t, H, L, G(DIFUSCO_W_TIME_FREQS), G(DIFUSCO_W_TIME0_W), G(DIFUSCO_W_TIME0_B),
+  const float* tbias = a->tbias ? a->tbias : ws.tbias;      // (caller-prepared rows of this t, or computed here)
+  if (!head_only && !a->tbias)
+  PROF(PROF_EMBED, launch_time_bias(&a->t, 1, H, L, G(DIFUSCO_W_TIME_FREQS), G(DIFUSCO_W_TIME0_W), G(DIFUSCO_W_TIME0_B),
                                     G(DIFUSCO_W_TIME2_W), G(DIFUSCO_W_TIME2_B), LW(0, 0), lo.layer_stride,
                                     lo.off[DIFUSCO_W_GLOBAL_COUNT + DIFUSCO_WL_TIME_W] - lo.off[DIFUSCO_W_GLOBAL_COUNT],
                                     lo.off[DIFUSCO_W_GLOBAL_COUNT + DIFUSCO_WL_TIME_B] - lo.off[DIFUSCO_W_GLOBAL_COUNT],
@@ -326,23 +354,28 @@ int difusco_denoise_step(const difusco_step_args* a) {
   if (head_only) {
     // (phase 2: e / h of the phase-1 call are still in the workspace)
   } else if (tsp) {
-    PROF(PROF_EMBED, launch_pos_embed(a->points, G(DIFUSCO_W_DIMT_POS), (int)N, H, ws.node4, st))
-    PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
-                                       H, H, H, st))
+    if (!use_prep) {
+      PROF(PROF_EMBED, launch_pos_embed(a->points, G(DIFUSCO_W_DIMT_POS), (int)N, H, ws.node4, st))
+      PROF(PROF_LINEAR_NODE, linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, ws.h, N,
+                                         H, H, H, st))
+    }
     if (fused)   // pad lanes of the last tiles must read as zero in every later kernel
       PROF(PROF_EMBED, zero_async(ws.e + (E / 32) * 32 * H, sizeof(float) * (E_pad - (E / 32) * 32) * H, st))
     if (a->xt_is_binary) {
-      PROF(PROF_EMBED, launch_scalar_embed(nullptr, nullptr, G(DIFUSCO_W_DIMT_SCALAR), 2, H, ws.table_in, st))
-      PROF(PROF_EMBED, launch_two_rows_linear(H, ws.table_in, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), ws.table,
-                                              st))
-      if (l0_fold) {   // e0 and C e0 are read from ws.table by the first fused layer: C on the two rows, exact fp32
-        PROF(PROF_EMBED, launch_two_rows_linear(H, ws.table, LW(0, DIFUSCO_WL_C_W), nullptr, ws.table + 2 * H, st))
+      if (!use_prep) {
+        PROF(PROF_EMBED, launch_scalar_embed(nullptr, nullptr, G(DIFUSCO_W_DIMT_SCALAR), 2, H, ws.table_in, st))
+        PROF(PROF_EMBED, launch_two_rows_linear(H, ws.table_in, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), ws.table,
+                                                st))
+      }
+      if (l0_fold) {   // e0 and C e0 are read from the table by the first fused layer: C on the two rows, exact fp32
+        if (!use_prep)
+          PROF(PROF_EMBED, launch_two_rows_linear(H, ws.table, LW(0, DIFUSCO_WL_C_W), nullptr, ws.table + 2 * H, st))
       }
       else if (fused) {
-        PROF(PROF_EMBED, launch_table_rows_tiled(a->xt, a->perm, ws.table, E, ws.e, st))
+        PROF(PROF_EMBED, launch_table_rows_tiled(a->xt, a->perm, table, E, ws.e, st))
         if (f16) PROF(PROF_EMBED, launch_tile_absmax_tiled(ws.e, n_tiles_pad, ws.etmax, st))
       }
-      else PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, ws.table, E, H, ws.e, st))
+      else PROF(PROF_EMBED, launch_table_rows(a->xt, a->perm, table, E, H, ws.e, st))
     } else {
       if (fused) {   // sinusoidal features generated inside the linear: the E x H embedding never exists in memory
         const unsigned short* pl = reinterpret_cast<const unsigned short*>(G(DIFUSCO_W_EDGE_EMBED_PLANES)) +
@@ -373,6 +406,11 @@ int difusco_denoise_step(const difusco_step_args* a) {
   // the GNN layers (gnn_encoder.py:425-449)
   const long long split_off = a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0;  // fp16 planes follow bf16
   for (int l = 0; l < (head_only ? 0 : L); ++l) {
+    // layer 0 of a step with prepared state: U|V|A|B of h0 and h0 itself come from the prepared buffer
+    const bool prep_l = use_prep && l == 0;
+    const float* node4 = prep_l ? prep.node4_0 : ws.node4;
+    if (prep_l) {
+    } else
     if (a->precision != DIFUSCO_PREC_FP32 && H == 256) {   // node rows on the same split-precision matrix-core path
       const unsigned short* npl = reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_NODE4_PLANES)) +
                                   (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * 4 * H * H : 0);
@@ -390,38 +428,39 @@ int difusco_denoise_step(const difusco_step_args* a) {
     }
     if (fused && l == 0 && l0_fold) {
       PROF(PROF_LINEAR_EDGE,
-           launch_edge_layer_fused_l0(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,
+           launch_edge_layer_fused_l0(a->precision, ws.e, node4, a->row, a->col, (int)E,
                                       reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_C_PLANES)) + split_off,
                                       reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_OUT_PLANES)) + split_off,
                                       (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
-                                      LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
+                                      LW(l, DIFUSCO_WL_NORM_E_B), tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                       LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
-                                      ws.table, tsp ? a->xt : nullptr, tsp ? a->perm : nullptr,
-                                      LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st))
+                                      table, tsp ? a->xt : nullptr, tsp ? a->perm : nullptr,
+                                      LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st, reg_gather))
     } else if (fused && tail_fold && l == L - 1) {
       PROF(PROF_LINEAR_EDGE,
-           launch_edge_layer_fused_tail(a->precision, tsp ? 1 : 2, ws.e, ws.node4, a->row, a->col, (int)E,
+           launch_edge_layer_fused_tail(a->precision, tsp ? 1 : 2, ws.e, node4, a->row, a->col, (int)E,
                                       reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_C_PLANES)) + split_off,
                                       reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_OUT_PLANES)) + split_off,
                                       (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
-                                      LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
+                                      LW(l, DIFUSCO_WL_NORM_E_B), tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                       LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
-                                      ws.gn_tile, LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st))
+                                      ws.gn_tile, LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st, reg_gather))
     } else if (fused) {
       PROF(PROF_LINEAR_EDGE,
-           launch_edge_layer_fused(a->precision, ws.e, ws.node4, a->row, a->col, (int)E,
+           launch_edge_layer_fused(a->precision, ws.e, node4, a->row, a->col, (int)E,
                                    reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_C_PLANES)) + split_off,
                                    reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_OUT_PLANES)) + split_off,
                                    (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
-                                   LW(l, DIFUSCO_WL_NORM_E_B), ws.tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
+                                   LW(l, DIFUSCO_WL_NORM_E_B), tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                    LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
-                                   LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, ws.etmax, st))
+                                   LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, ws.etmax, st, reg_gather))
     }
     if (fused && gn_fold && l == L - 1) continue;     // TSP: h is not read after the last layer
     if (fused) {
-      PROF(PROF_GATE, launch_node_finalize((int)N, (int)E, a->rowptr, ws.node4, ws.part, ws.direct, ws.h,
+      PROF(PROF_GATE, launch_node_finalize((int)N, (int)E, a->rowptr, node4, ws.part, ws.direct, ws.h,
                                            LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
-                                           ws.tbias + (size_t)l * H, tsp ? 1 : 0, f16 ? ws.hscale : nullptr, st))
+                                           tbias + (size_t)l * H, tsp ? 1 : 0, f16 ? ws.hscale : nullptr, st,
+                                           prep_l ? prep.h0 : nullptr))
       continue;
     }
     PROF(PROF_LINEAR_EDGE, edge_linear(ws.e, LW(l, DIFUSCO_WL_C_W), LW(l, DIFUSCO_WL_C_PLANES), LW(l, DIFUSCO_WL_C_B),
@@ -430,7 +469,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                                LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
                                                LW(l, DIFUSCO_WL_NORM_E_W), LW(l, DIFUSCO_WL_NORM_E_B),
                                                LW(l, DIFUSCO_WL_OUT_LN_W), LW(l, DIFUSCO_WL_OUT_LN_B),
-                                               ws.tbias + (size_t)l * H, tsp ? 1 : 0, st))
+                                               tbias + (size_t)l * H, tsp ? 1 : 0, st))
     PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, LW(l, DIFUSCO_WL_OUT_W), LW(l, DIFUSCO_WL_OUT_PLANES),
                                        LW(l, DIFUSCO_WL_OUT_B), ws.e, ws.e))
   }
@@ -468,6 +507,78 @@ int difusco_denoise_step(const difusco_step_args* a) {
                               a->gn_phase, a->gn_sums))
 #undef PROF
   return finish();
+}
+
+size_t difusco_prepared_bytes(int hidden, int n_nodes) {
+  if (!hidden_ok(hidden) || n_nodes <= 0) return 0;
+  return carve_prepared(nullptr, hidden, n_nodes).bytes;
+}
+
+int difusco_time_bias_rows(int hidden, int n_layers, int out_channels, const float* weights, const float* t_host, int n_t,
+                           float* out, void* stream) {
+  using namespace difusco;
+  if (!hidden_ok(hidden) || n_layers < 1 || (out_channels != 1 && out_channels != 2))
+    return fail(DIFUSCO_EINVAL, "hidden in {64,128,256}, n_layers >= 1, out_channels in {1,2} required");
+  if (!weights || !t_host || !out || n_t < 1) return fail(DIFUSCO_EINVAL, "null pointer or n_t < 1");
+  const Layout lo = make_layout(hidden, n_layers, out_channels);
+  auto G = [&](int id) { return weights + lo.off[id]; };
+  HIP_TRY(launch_time_bias(t_host, n_t, hidden, n_layers, G(DIFUSCO_W_TIME_FREQS), G(DIFUSCO_W_TIME0_W), G(DIFUSCO_W_TIME0_B),
+                           G(DIFUSCO_W_TIME2_W), G(DIFUSCO_W_TIME2_B), weights + lo.off[DIFUSCO_W_GLOBAL_COUNT], lo.layer_stride,
+                           lo.off[DIFUSCO_W_GLOBAL_COUNT + DIFUSCO_WL_TIME_W] - lo.off[DIFUSCO_W_GLOBAL_COUNT],
+                           lo.off[DIFUSCO_W_GLOBAL_COUNT + DIFUSCO_WL_TIME_B] - lo.off[DIFUSCO_W_GLOBAL_COUNT], out,
+                           (hipStream_t)stream));
+  return DIFUSCO_OK;
+}
+
+// The step-invariant part of a TSP step, with the kernels (and therefore the bits) of the stateless step: node embedding,
+// row scales, layer 0's node linear, the two-row edge-input table and C of layer 0 applied to it.
+int difusco_prepare(const difusco_step_args* a, void* prepared, size_t prepared_bytes) {
+  using namespace difusco;
+  if (!a || !prepared) return fail(DIFUSCO_EINVAL, "null args / buffer");
+  if (a->struct_size != sizeof(difusco_step_args) || a->abi_version != DIFUSCO_ABI_VERSION)
+    return fail(DIFUSCO_EINVAL, "ABI mismatch: struct_size %u (want %zu), abi %u (want %d)", a->struct_size,
+                sizeof(difusco_step_args), a->abi_version, DIFUSCO_ABI_VERSION);
+  const int H = a->hidden, L = a->n_layers, C = a->out_channels;
+  if (!hidden_ok(H) || L < 1 || (C != 1 && C != 2)) return fail(DIFUSCO_EINVAL, "bad model shape");
+  if (a->task != DIFUSCO_TASK_TSP) return fail(DIFUSCO_EINVAL, "prepared state exists for TSP only (the MIS node embedding is a function of x_t)");
+  const int64_t N = a->n_nodes, E = a->n_edges;
+  if (N <= 0 || E < 0 || !a->weights || !a->points || !a->workspace) return fail(DIFUSCO_EINVAL, "null pointer / empty graph");
+  if (a->precision < DIFUSCO_PREC_FP32 || a->precision > DIFUSCO_PREC_FP16X3) return fail(DIFUSCO_EINVAL, "unknown precision %d", a->precision);
+  const Prepared prep = carve_prepared(prepared, H, N);
+  if (prep.bytes > prepared_bytes) return fail(DIFUSCO_EWORKSPACE, "prepared buffer too small: %zu < %zu", prepared_bytes, prep.bytes);
+  const int nblk = gn_blocks_for(E > N ? E : N);
+  Workspace ws = carve(a->workspace, H, L, N, E, a->n_segments < 1 ? 1 : a->n_segments, nblk);
+  if (ws.bytes > a->workspace_bytes) return fail(DIFUSCO_EWORKSPACE, "workspace too small: %zu < %zu", a->workspace_bytes, ws.bytes);
+  const Layout lo = make_layout(H, L, C);
+  const float* W = a->weights;
+  auto G = [&](int id) { return W + lo.off[id]; };
+  auto LW = [&](int l, int id) { return W + lo.off[DIFUSCO_W_GLOBAL_COUNT + l * DIFUSCO_WL_COUNT + id]; };
+  hipStream_t st = (hipStream_t)a->stream;
+  const bool f16 = a->precision == DIFUSCO_PREC_FP16X3;
+  // h0 = node_embed(pos_embed(points))  (ws.node4 is the scratch of the sinusoidal features, as in the step)
+  HIP_TRY(launch_pos_embed(a->points, G(DIFUSCO_W_DIMT_POS), (int)N, H, ws.node4, st));
+  HIP_TRY(linear_rows(ws.node4, G(DIFUSCO_W_NODE_EMBED_W), G(DIFUSCO_W_NODE_EMBED_B), nullptr, prep.h0, N, H, H, H, st));
+  // layer 0's U|V|A|B rows of h0
+  if (a->precision != DIFUSCO_PREC_FP32 && H == 256) {
+    const unsigned short* npl = reinterpret_cast<const unsigned short*>(LW(0, DIFUSCO_WL_NODE4_PLANES)) +
+                                (f16 ? (long long)3 * 4 * H * H : 0);
+    SplitScale sc;
+    if (f16) {
+      HIP_TRY(launch_row_pow2_scale(prep.h0, N, H, ws.hscale, st));
+      sc.row_scale = ws.hscale;
+      sc.w_inv = LW(0, DIFUSCO_WL_NODE4_PLANES) + (long long)5 * 4 * H * H / 2;
+    }
+    HIP_TRY(linear_rows_split(prep.h0, npl, (long long)4 * H * H, a->precision, LW(0, DIFUSCO_WL_NODE4_B), nullptr,
+                              prep.node4_0, N, H, 4 * H, 4 * H, st, 0, sc));
+  } else {
+    HIP_TRY(linear_rows(prep.h0, LW(0, DIFUSCO_WL_NODE4_W), LW(0, DIFUSCO_WL_NODE4_B), nullptr, prep.node4_0, N, H, 4 * H,
+                        4 * H, st));
+  }
+  // two-row edge-input table of a categorical step (embedding of the bit) and C of layer 0 applied to it
+  HIP_TRY(launch_scalar_embed(nullptr, nullptr, G(DIFUSCO_W_DIMT_SCALAR), 2, H, ws.table_in, st));
+  HIP_TRY(launch_two_rows_linear(H, ws.table_in, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), prep.table, st));
+  HIP_TRY(launch_two_rows_linear(H, prep.table, LW(0, DIFUSCO_WL_C_W), nullptr, prep.table + 2 * H, st));
+  return DIFUSCO_OK;
 }
 
 int difusco_linear_rows(const float* x, const float* w, const float* bias, const float* residual, float* y, int64_t m,
@@ -532,7 +643,6 @@ int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int3
     return fail(DIFUSCO_EINVAL, "null pointer");
   if (precision == DIFUSCO_PREC_FP16X3 && !scales)
     return fail(DIFUSCO_EINVAL, "fused kernel, FP16X3: the operand-scale record of the layer is required");
-  if (n_nodes >= (1 << 20)) return fail(DIFUSCO_EUNSUPPORTED, "fused kernel: n_nodes must be < 2^20");
   const long long off = precision == DIFUSCO_PREC_FP16X3 ? 3LL * 256 * 256 : 0;
   float* part = reinterpret_cast<float*>(scratch);
   float* direct = part + (fused_part_floats(n_edges) + 63) / 64 * 64;
@@ -545,7 +655,7 @@ int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int3
                                            reinterpret_cast<const unsigned short*>(planes_c) + off,
                                            reinterpret_cast<const unsigned short*>(planes_o) + off, 256LL * 256, b_c,
                                            norm_e_w, norm_e_b, tbias, out_ln_w, out_ln_b, b_out, time_on_edge, part,
-                                           direct, scales, etmax, etmax, st));
+                                           direct, scales, etmax, etmax, st, n_nodes >= (1 << 20) ? 1 : 0));
   HIP_TRY(difusco::launch_node_finalize(n_nodes, n_edges, rowptr, node4, part, direct, h, norm_h_w, norm_h_b, tbias,
                                         time_on_edge, nullptr, st));
   return DIFUSCO_OK;

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
                                                             const float* __restrict__ nh_w,
                                                             const float* __restrict__ nh_b,
                                                             const float* __restrict__ tbias, int time_on_edge,
-                                                            float* __restrict__ row_scale) {
+                                                            float* __restrict__ row_scale, const float* h_in) {
   constexpr int H = 256;
   const int lane = threadIdx.x & 63;
   const int f = lane * 4;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
   const v4f gw = *reinterpret_cast<const v4f*>(nh_w + f), gb = *reinterpret_cast<const v4f*>(nh_b + f);
   const v4f tb = *reinterpret_cast<const v4f*>(tbias + f);
   float* hp = h + (long long)i * H + f;
-  v4f hv = *reinterpret_cast<const v4f*>(hp);
+  v4f hv = *reinterpret_cast<const v4f*>(h_in + (long long)i * H + f);      // (h_in == h: in place)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float y = d[q] * rstd * gw[q] + gb[q];
@@ -77,8 +77,10 @@ unsigned long long* g_fused_dbg = nullptr;   // device buffer for phase timestam
 
 hipError_t launch_fused_fp16(int kind, FUSED_KIND_PARAMS) { return launch_fused_kind<FFp16>(kind, FUSED_KIND_ARGS); }
 
-static hipError_t launch_by_mode(int mode, int kind, FUSED_KIND_PARAMS) {
+// kind + 4: the register-gather instantiation of the same kind (calls with n_nodes >= 2^20)
+static hipError_t launch_by_mode(int mode, int kind, int reg_gather, FUSED_KIND_PARAMS) {
   if (n_edges <= 0) return hipSuccess;
+  if (reg_gather) kind += 4;
   if (mode == 1) return launch_fused_bf16(kind, FUSED_KIND_ARGS);     // DIFUSCO_PREC_BF16X3
   if (mode == 3) return launch_fused_fp16(kind, FUSED_KIND_ARGS);     // DIFUSCO_PREC_FP16X3
   return hipErrorInvalidValue;
@@ -90,7 +92,7 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
                                    long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                    const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                    int time_on_edge, float* part, float* direct, const float* scales,
-                                   const float* etmax_in, float* etmax_out, hipStream_t stream) {
+                                   const float* etmax_in, float* etmax_out, hipStream_t stream, int reg_gather) {
   const float *l0_table = nullptr, *l0_x = nullptr;
   const int* l0_perm = nullptr;
   float* gn_tile = nullptr;
@@ -100,7 +102,7 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
     return launch_fused_ablation(g_fused_ablate, FUSED_KIND_ARGS);
   }
 #endif
-  return launch_by_mode(mode, 0, FUSED_KIND_ARGS);
+  return launch_by_mode(mode, 0, reg_gather, FUSED_KIND_ARGS);
 }
 
 // Last layer of a step.  tail 1 (TSP: the head normalises e): the per-tile GroupNorm partial sums
@@ -111,12 +113,12 @@ hipError_t launch_edge_layer_fused_tail(int mode, int tail, float* e, const floa
                                         long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                         const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                         int time_on_edge, float* part, float* direct, float* gn_tile,
-                                        const float* scales, const float* etmax_in, hipStream_t stream) {
+                                        const float* scales, const float* etmax_in, hipStream_t stream, int reg_gather) {
   const float *l0_table = nullptr, *l0_x = nullptr;
   const int* l0_perm = nullptr;
   float* etmax_out = nullptr;
   if (tail != 1 && tail != 2) return hipErrorInvalidValue;
-  return launch_by_mode(mode, tail == 1 ? 2 : 3, FUSED_KIND_ARGS);
+  return launch_by_mode(mode, tail == 1 ? 2 : 3, reg_gather, FUSED_KIND_ARGS);
 }
 
 // First layer of a step whose edge input is a table lookup (see the L0 notes in the kernel): same as
@@ -127,20 +129,22 @@ hipError_t launch_edge_layer_fused_l0(int mode, float* e, const float* node4, co
                                       long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                       const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                       int time_on_edge, float* part, float* direct, const float* table, const float* x,
-                                      const int* perm, const float* scales, float* etmax_out, hipStream_t stream) {
+                                      const int* perm, const float* scales, float* etmax_out, hipStream_t stream,
+                                      int reg_gather) {
   const float *l0_table = table, *l0_x = x;
   const int* l0_perm = perm;
   float* gn_tile = nullptr;
   const float* etmax_in = nullptr;
-  return launch_by_mode(mode, 1, FUSED_KIND_ARGS);
+  return launch_by_mode(mode, 1, reg_gather, FUSED_KIND_ARGS);
 }
 
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
-                                const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream) {
+                                const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream,
+                                const float* h_in) {
   if (n_nodes <= 0) return hipSuccess;
   hipLaunchKernelGGL(node_finalize_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, stream, n_nodes, n_edges,
-                     rowptr, node4, part, direct, h, nh_w, nh_b, tbias, time_on_edge, row_scale);
+                     rowptr, node4, part, direct, h, nh_w, nh_b, tbias, time_on_edge, row_scale, h_in ? h_in : h);
   return hipGetLastError();
 }
 

@@ -1287,7 +1287,7 @@ hipError_t launch_fused_opt(A... args) {
 
 // one entry point per element type / purpose, each defined in its own translation unit.
 // kind: 0 middle layer, 1 first layer from the 2-row table (L0), 2 last layer of a TSP step (GNP, TAIL 1),
-//       3 last layer of a MIS step (TAIL 2)
+//       3 last layer of a MIS step (TAIL 2);  + 4: the register-gather instantiation (n_nodes >= 2^20)
 #define FUSED_KIND_PARAMS                                                                                              \
   float *e, const float *node4, const int *row, const int *col, int n_edges, const unsigned short *c_planes,          \
       const unsigned short *o_planes, long long plane_stride, const float *b_c, const float *g_e, const float *b_e,   \
@@ -1301,6 +1301,9 @@ hipError_t launch_fused_fp16(int kind, FUSED_KIND_PARAMS);
 hipError_t launch_fused_bf16(int kind, FUSED_KIND_PARAMS);
 hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS);      // profiling-only variants of the fp16 middle layer
 
+// kinds 4-7 = kinds 0-3 with the neighbour-table rows gathered into REGISTERS by 64-bit addresses (round 2's option set):
+// the full-line gathers address node rows by 32-bit byte offsets (4 KB per row), which wrap at n_nodes = 2^20.  The step
+// driver (api.hip) picks these for such calls; results are bit-identical to the full-line kernels.
 template <typename T>
 hipError_t launch_fused_kind(int kind, FUSED_KIND_PARAMS) {
   switch (kind) {
@@ -1308,6 +1311,10 @@ hipError_t launch_fused_kind(int kind, FUSED_KIND_PARAMS) {
     case 1: return launch_fused_opt<T, true, false, 0>(FUSED_KIND_ARGS);
     case 2: return launch_fused_opt<T, false, true, 1>(FUSED_KIND_ARGS);
     case 3: return launch_fused_opt<T, false, false, 2>(FUSED_KIND_ARGS);
+    case 4: return launch_fused_t<T, 0, FUSED_NW, false, false, 0, FUSED_OPT_R2>(FUSED_KIND_ARGS);
+    case 5: return launch_fused_t<T, 0, FUSED_NW, true, false, 0, FUSED_OPT_R2>(FUSED_KIND_ARGS);
+    case 6: return launch_fused_t<T, 0, FUSED_NW, false, true, 1, FUSED_OPT_R2>(FUSED_KIND_ARGS);
+    case 7: return launch_fused_t<T, 0, FUSED_NW, false, false, 2, FUSED_OPT_R2>(FUSED_KIND_ARGS);
     default: return hipErrorInvalidValue;
   }
 }

@@ -76,7 +76,10 @@ __device__ __forceinline__ Vec<VEC> wave_layer_norm(const Vec<VEC>& x, const Vec
 // (models/nn.py:103-121, gnn_encoder.py:311-315, :329-337).  One workgroup per layer; one [1,H]
 // row per layer per step, so this is latency-, not bandwidth-relevant.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void time_bias_kernel(float t, int H, const float* __restrict__ freqs,
+struct TimeBatch {      // up to 64 diffusion times per launch (blockIdx.y selects one)
+  float t[64];
+};
+__global__ __launch_bounds__(256) void time_bias_kernel(TimeBatch tb, int H, const float* __restrict__ freqs,
                                                         const float* __restrict__ w0, const float* __restrict__ b0,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         const float* __restrict__ wl_base, long long layer_stride,
@@ -86,6 +89,8 @@ __global__ __launch_bounds__(256) void time_bias_kernel(float t, int H, const fl
   __shared__ float te[128];
   const int half = H / 2;
   const int tid = threadIdx.x;
+  const float t = tb.t[blockIdx.y];
+  tbias += (long long)blockIdx.y * gridDim.x * H;      // rows of time blockIdx.y: [n_layers, H]
   for (int k = tid; k < half; k += 256) {
     const float a = t * freqs[k];
     emb[k] = cosf(a);
@@ -600,13 +605,20 @@ __global__ __launch_bounds__(256) void head_apply_tiled_kernel(const float* __re
     default: return hipErrorInvalidValue;  \
   }
 
-hipError_t launch_time_bias(float t, int H, int n_layers, const float* freqs, const float* w0, const float* b0,
-                            const float* w2, const float* b2, const float* wl_base, long long layer_stride,
+hipError_t launch_time_bias(const float* t_host, int n_t, int H, int n_layers, const float* freqs, const float* w0,
+                            const float* b0, const float* w2, const float* b2, const float* wl_base, long long layer_stride,
                             long long wl_w_off, long long wl_b_off, float* tbias, hipStream_t stream) {
-  if (H > 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(time_bias_kernel, dim3(n_layers), dim3(256), 0, stream, t, H, freqs, w0, b0, w2, b2, wl_base,
-                     layer_stride, wl_w_off, wl_b_off, tbias);
-  return hipGetLastError();
+  if (H > 256 || n_t < 1) return hipErrorInvalidValue;
+  for (int first = 0; first < n_t; first += 64) {      // the times travel as kernel arguments: no device copy, capture safe
+    TimeBatch tb;
+    const int n = n_t - first < 64 ? n_t - first : 64;
+    for (int i = 0; i < 64; ++i) tb.t[i] = t_host[first + (i < n ? i : 0)];
+    hipLaunchKernelGGL(time_bias_kernel, dim3(n_layers, n), dim3(256), 0, stream, tb, H, freqs, w0, b0, w2, b2, wl_base,
+                       layer_stride, wl_w_off, wl_b_off, tbias + (long long)first * n_layers * H);
+    hipError_t er = hipGetLastError();
+    if (er != hipSuccess) return er;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_pos_embed(const float* points, const float* dimt, int n_nodes, int H, float* out, hipStream_t stream) {

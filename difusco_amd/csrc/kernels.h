@@ -73,19 +73,22 @@ hipError_t launch_edge_layer_fused(int mode, float* e, const float* node4, const
                                    long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                    const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                    int time_on_edge, float* part, float* direct, const float* scales,
-                                   const float* etmax_in, float* etmax_out, hipStream_t stream);
+                                   const float* etmax_in, float* etmax_out, hipStream_t stream, int reg_gather = 0);
 hipError_t launch_edge_layer_fused_l0(int mode, float* e, const float* node4, const int* row, const int* col, int n_edges,
                                       const unsigned short* c_planes, const unsigned short* o_planes,
                                       long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                       const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                       int time_on_edge, float* part, float* direct, const float* table, const float* x,
-                                      const int* perm, const float* scales, float* etmax_out, hipStream_t stream);
+                                      const int* perm, const float* scales, float* etmax_out, hipStream_t stream,
+                                      int reg_gather = 0);
 hipError_t launch_edge_layer_fused_tail(int mode, int tail, float* e, const float* node4, const int* row, const int* col,
                                         int n_edges, const unsigned short* c_planes, const unsigned short* o_planes,
                                         long long plane_stride, const float* b_c, const float* g_e, const float* b_e,
                                         const float* tbias, const float* g_o, const float* b_o, const float* b_out,
                                         int time_on_edge, float* part, float* direct, float* gn_tile,
-                                        const float* scales, const float* etmax_in, hipStream_t stream);
+                                        const float* scales, const float* etmax_in, hipStream_t stream, int reg_gather = 0);
+// reg_gather != 0: the variant of the kernel that gathers neighbour-table rows into registers by 64-bit addresses - for calls
+// with n_nodes >= 2^20, where the 32-bit byte offsets of the full-line (LDS-DMA) gathers would wrap (4 KB per node row)
 #ifdef DIFUSCO_PROFILING
 extern int g_fused_ablate;
 extern int g_fused_lds_pad;
@@ -95,12 +98,16 @@ extern int g_node_linear_depth;
 extern int g_node_linear_ablate;
 extern unsigned long long* g_fused_dbg;
 #endif
+// h_in: the node state the update is added to (nullptr = h itself, in place; layer 0 of a step with prepared state reads the
+// prepared h0 and writes the workspace h)
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
-                                const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream);
+                                const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream,
+                                const float* h_in = nullptr);
 
-hipError_t launch_time_bias(float t, int H, int n_layers, const float* freqs, const float* w0, const float* b0,
-                            const float* w2, const float* b2, const float* wl_base, long long layer_stride,
+// tbias[i][l][:] = time_layer_l(time_embed(timestep_embedding(t_host[i]))) for n_t diffusion times (HOST array)
+hipError_t launch_time_bias(const float* t_host, int n_t, int H, int n_layers, const float* freqs, const float* w0,
+                            const float* b0, const float* w2, const float* b2, const float* wl_base, long long layer_stride,
                             long long wl_w_off, long long wl_b_off, float* tbias, hipStream_t stream);
 hipError_t launch_pos_embed(const float* points, const float* dimt, int n_nodes, int H, float* out, hipStream_t stream);
 hipError_t launch_scalar_embed(const float* x, const int* perm, const float* dimt, long long rows, int H, float* out,

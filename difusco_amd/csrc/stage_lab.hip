@@ -1,0 +1,365 @@
+// Stage-loop laboratory (PROFILING library only): GEMM 1 of the fused edge layer - Ce = C e on the tiled e stream, fp16x3
+// split products, weight planes streamed through LDS by LDS-DMA - and NOTHING else, in several workgroup geometries and
+// synchronisation schemes.  It exists to answer one question with measurements before the production kernel
+// (edge_layer_kernel.h) is touched: what does the weight-stage loop cost in each geometry ("GEMM-only
+// ablation first each time")?  Same operand layouts as the production kernel (plane slabs of weights.py, wslot swizzle,
+// tiled e), real results (scripts/bench_stage_lab.py checks them against a float64 product), so every variant is a
+// drop-in candidate for the production stage loop.
+//
+// Template parameters of a variant:
+//   EPW   edges per wave: 32 (one B tile per weight fragment, production) or 64 (two B tiles against every ds_read_b128
+//         of a weight fragment: half the LDS reads and half the L2 -> LDS weight stream per edge, 48 MFMAs per stage)
+//   WAVES waves per workgroup: 4 or 8 (8 waves share one weight stream: 256 edges per pass at 32 edges per wave)
+//   NBUF  weight stage buffers (16 KiB each): 2 = double buffer (production), 3 / 4 = one / two stages in flight across
+//         the stage barrier
+//   SYNC  0: s_waitcnt vmcnt + __syncthreads() per stage (production);  1: raw s_barrier + counted vmcnt (the newest
+//         requests stay in flight across the barrier);  2: no barrier - per-wave LDS flags ("stage s landed" / "stage s
+//         read"), a wave starts stage t+1 when ITS data has landed, whatever its siblings are doing
+//   RING  e slabs (register ring) in flight per tile
+//   PRIO  1: s_setprio 1 around every MFMA group
+//   MINB  workgroups per CU the register budget is sized for (__launch_bounds__ second argument): 2 -> <= 256 registers,
+//         1 -> up to 512 (one wave per SIMD with 4-wave workgroups)
+#include "edge_layer_common.h"
+
+#ifdef DIFUSCO_PROFILING
+#include "../../include/difusco_hip.h"
+
+namespace difusco {
+namespace lab {
+
+constexpr int H = 256;
+constexpr int NS = 16;                 // stages = k slabs of C
+constexpr int PLANE = 256 * 16;        // 16-bit elements per plane per stage
+constexpr int BUF = 2 * PLANE;         // elements per stage buffer (two planes, 16 KiB)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter on gfx9");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+// VMEM operations of one wave that may still be in flight at the end of stage t when everything up to and including the
+// requests of weight stage t+1 must have landed (requests complete in order).  Issue order: e ring fill, weight stages
+// 0 .. DIST-1 (prologue); then per stage s: weight stage s+DIST, e slab s+RING.
+template <int TPW, int PPW, int DIST, int RING>
+constexpr int allowed_in_flight(int t) {
+  int pos = RING * 2 * TPW;
+  int dma_end[NS + 8] = {};
+  for (int s = 0; s < DIST && s < NS; ++s) {
+    pos += PPW;
+    dma_end[s] = pos;
+  }
+  for (int st = 0; st <= t; ++st) {
+    if (st + DIST < NS) {
+      pos += PPW;
+      dma_end[st + DIST] = pos;
+    }
+    if (st + RING < NS) pos += 2 * TPW;
+  }
+  return pos - dma_end[t + 1];
+}
+
+// SYNC 2: spin until every one of the WAVES monotone counters at `f` (LDS, 16-byte aligned) has reached `need`
+template <int WAVES>
+__device__ __forceinline__ void lab_flags_wait(volatile int* f, int need) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  while (true) {
+    v4i a = *reinterpret_cast<volatile v4i*>(f);
+    int mn = min(min(a[0], a[1]), min(a[2], a[3]));
+    if constexpr (WAVES == 8) {
+      v4i b = *reinterpret_cast<volatile v4i*>(f + 4);
+      mn = min(mn, min(min(b[0], b[1]), min(b[2], b[3])));
+    }
+    if (__builtin_amdgcn_readfirstlane(mn) >= need) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+template <int EPW, int WAVES, int NBUF, int SYNC, int RING, int PRIO, int MINB, int DIST>
+__global__ __launch_bounds__(64 * WAVES, MINB) void stage_lab_kernel(const float* __restrict__ e,
+                                                                     const unsigned short* __restrict__ c_planes,
+                                                                     long long plane_stride, float* __restrict__ out,
+                                                                     int n_tiles, float inv_c, int do_store) {
+  typedef FFp16 T;
+  typedef typename T::frag frag;
+  constexpr int TPW = EPW / 32;          // 32-edge tiles per wave
+  constexpr int PP = 8 / WAVES;          // 1 KiB LDS-DMA pieces per wave, plane and stage
+  constexpr int PPW = 2 * PP;            // ... per wave and stage
+  static_assert(EPW == 32 || EPW == 64, "");
+  static_assert(WAVES == 4 || WAVES == 8, "");
+  static_assert(SYNC != 0 || NBUF == 2, "the __syncthreads() scheme is the double buffer");
+  // DIST = stages a weight request is issued ahead of its use.  With a stage barrier (SYNC 0 / 1) every buffer is free as
+  // soon as the barrier is passed: DIST = NBUF - 1.  With flags (SYNC 2) the spare buffers are SLACK: DIST < NBUF - 1 lets
+  // a wave run up to NBUF - 1 - DIST stages ahead of the slowest sibling before it has to wait for a free buffer.
+  static_assert(DIST >= 1 && DIST <= NBUF - 1 && (SYNC == 2 || DIST == NBUF - 1), "");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* wbuf = reinterpret_cast<unsigned short*>(smem_raw);
+  // SYNC 2: flags[0][w] = weight stages whose pieces issued by wave w have landed, flags[1][w] = stages wave w has finished
+  // reading (monotone counters, one writer each)
+  volatile int* flags = reinterpret_cast<volatile int*>(smem_raw + NBUF * BUF * 2);
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  {      // XCD-contiguous tile ranges (cdna_hip_programming.md T1, bijective)
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  const int tile0 = (bid * WAVES + wave) * TPW;
+  (void)n_tiles;
+  const int loff_b = lane * 16;
+
+  if constexpr (SYNC == 2) {
+    if (tid < 2 * WAVES) flags[tid] = 0;
+  }
+
+  // ---- weight stage requests (the production mapping: edge_layer_kernel.h FUSED_DMA_PIECE) ----
+  unsigned dvoff;
+  {
+    const int entry0 = (PP * wave) * 32 + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
+    dvoff = (entry0 >> 8) * 4096 + (entry0 & 255) * 16 + half * 8;
+  }
+  const __amdgpu_buffer_rsrc_t rs_c =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c_planes), 0, 0x7fffffff, 0x00020000);
+  const int plane_bytes = (int)plane_stride * 2;
+#define LAB_DMA_STAGE(t)                                                                                              \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) _Pragma("unroll") for (int i = 0; i < PP; ++i)                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                     \
+            rs_c, (__attribute__((address_space(3))) void*)(wbuf + ((t) % NBUF) * BUF + pl * PLANE + (PP * wave + i) * 512), \
+            16, dvoff * 2, (t)*4096 * 2 + pl * plane_bytes + i * 512 * 2, 0, 0);                                      \
+  }
+
+  // ---- e stream: register ring, RING slabs per tile ----
+  v4f er[TPW][RING][2];
+  __amdgpu_buffer_rsrc_t rs_e[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u)
+    rs_e[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e) + (long long)(tile0 + u) * (32 * H), 0, 32 * H * 4,
+                                                0x00020000);
+#define LAB_E_LOAD(u, ks)                                                                                           \
+  {                                                                                                                 \
+    er[u][(ks) % RING][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_e[u], loff_b, (ks)*2048, 0)); \
+    er[u][(ks) % RING][1] =                                                                                         \
+        __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_e[u], loff_b, (ks)*2048 + 1024, 0));      \
+  }
+#pragma unroll
+  for (int d = 0; d < RING; ++d)
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) LAB_E_LOAD(u, d)
+#pragma unroll
+  for (int s = 0; s < DIST; ++s) LAB_DMA_STAGE(s)
+
+  v16f acc[TPW][8];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u)
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][nb][r] = 0.0f;
+
+  const int a_off = wslot(l31, hh);
+
+  // first stage landed (every wave's pieces)
+  if constexpr (SYNC == 2) {
+    wait_vmcnt<(DIST - 1) * PPW>();
+    __builtin_amdgcn_s_barrier();      // (the flag words were zeroed above; one barrier per tile, none per stage)
+  } else if constexpr (SYNC == 1) {
+    wait_vmcnt<(DIST - 1) * PPW>();
+    __builtin_amdgcn_s_barrier();
+  } else {
+    wait_vmcnt<0>();
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    // B operands of slab t
+    frag xh[TPW], xl[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const v4f c0 = er[u][t % RING][0], c1 = er[u][t % RING][1];
+      const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      split8<T>(xs, xh[u], xl[u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SYNC == 2) {
+      // buffer (t + DIST) % NBUF held stage t + DIST - NBUF: every wave must have finished reading it
+      if (t + DIST - NBUF >= 0 && t + DIST < NS) lab_flags_wait<WAVES>(flags + WAVES, t + DIST - NBUF + 1);
+    }
+    if (t + DIST < NS) LAB_DMA_STAGE(t + DIST)
+    if (t + RING < NS) {
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) LAB_E_LOAD(u, t + RING)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SYNC == 2) {
+      if (t >= 1) {      // stage t: every wave's pieces landed?  (stage 0 was met by the barrier above)
+        lab_flags_wait<WAVES>(flags, t);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const unsigned short* wb = wbuf + (t % NBUF) * BUF + a_off;
+    frag fh[4], fl[4];
+#define LAB_FRAG(bi, slot)                                                      \
+  {                                                                             \
+    fh[slot] = *reinterpret_cast<const frag*>(wb + (bi)*32 * 16);               \
+    fl[slot] = *reinterpret_cast<const frag*>(wb + PLANE + (bi)*32 * 16);       \
+  }
+    LAB_FRAG(0, 0)
+    LAB_FRAG(1, 1)
+#pragma unroll
+    for (int bp = 0; bp < 4; ++bp) {
+      if (bp + 1 < 4) {
+        LAB_FRAG(2 * bp + 2, 2 * ((bp + 1) & 1))
+        LAB_FRAG(2 * bp + 3, 2 * ((bp + 1) & 1) + 1)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(1);
+      const int s0 = 2 * (bp & 1), s1 = s0 + 1, n0 = 2 * bp, n1 = n0 + 1;
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) {
+        acc[u][n0] = T::mfma(fl[s0], xh[u], acc[u][n0]);
+        acc[u][n1] = T::mfma(fl[s1], xh[u], acc[u][n1]);
+      }
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) {
+        acc[u][n0] = T::mfma(fh[s0], xl[u], acc[u][n0]);
+        acc[u][n1] = T::mfma(fh[s1], xl[u], acc[u][n1]);
+      }
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) {
+        acc[u][n0] = T::mfma(fh[s0], xh[u], acc[u][n0]);
+        acc[u][n1] = T::mfma(fh[s1], xh[u], acc[u][n1]);
+      }
+      if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef LAB_FRAG
+    if (t + 1 < NS) {
+      if constexpr (SYNC == 0) {
+        if (t + RING < NS) wait_vmcnt<2 * TPW>(); else wait_vmcnt<0>();
+        __syncthreads();
+      } else {
+        constexpr int kTab[NS] = {
+            allowed_in_flight<TPW, PPW, DIST, RING>(0),  allowed_in_flight<TPW, PPW, DIST, RING>(1),
+            allowed_in_flight<TPW, PPW, DIST, RING>(2),  allowed_in_flight<TPW, PPW, DIST, RING>(3),
+            allowed_in_flight<TPW, PPW, DIST, RING>(4),  allowed_in_flight<TPW, PPW, DIST, RING>(5),
+            allowed_in_flight<TPW, PPW, DIST, RING>(6),  allowed_in_flight<TPW, PPW, DIST, RING>(7),
+            allowed_in_flight<TPW, PPW, DIST, RING>(8),  allowed_in_flight<TPW, PPW, DIST, RING>(9),
+            allowed_in_flight<TPW, PPW, DIST, RING>(10), allowed_in_flight<TPW, PPW, DIST, RING>(11),
+            allowed_in_flight<TPW, PPW, DIST, RING>(12), allowed_in_flight<TPW, PPW, DIST, RING>(13),
+            allowed_in_flight<TPW, PPW, DIST, RING>(14), 0};
+        // (switch on the unrolled t: the wait needs an immediate)
+        switch (kTab[t]) {
+#define LAB_W(n) case n: wait_vmcnt<n>(); break;
+          LAB_W(0) LAB_W(1) LAB_W(2) LAB_W(3) LAB_W(4) LAB_W(5) LAB_W(6) LAB_W(7) LAB_W(8) LAB_W(9) LAB_W(10) LAB_W(11)
+          LAB_W(12) LAB_W(13) LAB_W(14) LAB_W(15) LAB_W(16) LAB_W(17) LAB_W(18) LAB_W(19) LAB_W(20) LAB_W(21) LAB_W(22)
+          LAB_W(23) LAB_W(24) LAB_W(25) LAB_W(26) LAB_W(27) LAB_W(28) LAB_W(29) LAB_W(30) LAB_W(31) LAB_W(32)
+#undef LAB_W
+          default: wait_vmcnt<0>(); break;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SYNC == 1) {
+          __builtin_amdgcn_s_barrier();
+        } else {
+          // publish: my pieces of stage t+1 have landed, I have finished reading stage t
+          if (lane == 0) {
+            flags[wave] = t + 1;
+            flags[WAVES + wave] = t + 1;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#undef LAB_DMA_STAGE
+#undef LAB_E_LOAD
+
+  // out (tiled like e) = acc / 2^kc
+  if (do_store) {
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      float* ot = out + (long long)(tile0 + u) * (32 * H) + lane * 4;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          v4f v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = acc[u][nb][4 * g + q] * inv_c;
+          __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(ot + (2 * nb + (g >> 1)) * 512 + (g & 1) * 256));
+        }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < TPW; ++u)
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) asm volatile("" ::"v"(acc[u][nb]));
+  }
+}
+
+template <int EPW, int WAVES, int NBUF, int SYNC, int RING, int PRIO, int MINB, int DIST = NBUF - 1>
+hipError_t launch(const float* e, const unsigned short* planes, float* out, int n_edges, float inv_c, int do_store,
+                  int lds_pad, hipStream_t st) {
+  auto kern = stage_lab_kernel<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST>;
+  static std::atomic<unsigned long long> attr_devices{0};
+  hipError_t er = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(kern), 160 * 1024);
+  if (er != hipSuccess) return er;
+  const int per_wg = EPW * WAVES;
+  if (n_edges % per_wg != 0) return hipErrorInvalidValue;
+  const int lds = NBUF * BUF * 2 + 256 + lds_pad;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n_edges / per_wg)), dim3(64 * WAVES), lds, st, e, planes, (long long)H * H, out,
+                     n_edges / 32, inv_c, do_store);
+  return hipGetLastError();
+}
+
+}  // namespace lab
+}  // namespace difusco
+
+extern "C" {
+// variant = EPW/32 * 100000 + WAVES * 10000 + NBUF * 1000 + SYNC * 100 + RING * 10 + PRIO; MINB follows from the geometry
+// (64-edge waves and 8-wave workgroups are one workgroup per CU, the production geometry two).  planes: the fp16 hi | lo
+// planes of C (weights.split_planes output + 3 H H 16-bit elements); e / out tiled [n_edges, 256]; n_edges a multiple of the
+// edges per workgroup.  lds_pad: extra dynamic LDS bytes (to pin the number of co-resident workgroups).
+int difusco_lab_gemm1(int variant, const float* e, const void* planes, float* out, int n_edges, float inv_c, int do_store,
+                      int lds_pad, void* stream) {
+  using namespace difusco::lab;
+  const unsigned short* pl = reinterpret_cast<const unsigned short*>(planes);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t er = hipErrorInvalidValue;
+#define LAB_CASE(code, EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB) \
+  case code: er = launch<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
+#define LAB_CASE_D(code, EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST) \
+  case code: er = launch<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
+  switch (variant) {
+    // production geometry: 32 edges per wave, 4 waves, two workgroups per CU
+    LAB_CASE(142020, 32, 4, 2, 0, 2, 0, 2)      // production scheme (double buffer, vmcnt + __syncthreads)
+    LAB_CASE(142120, 32, 4, 2, 1, 2, 0, 2)      // raw barrier, counted waits, double buffer
+    LAB_CASE(143120, 32, 4, 3, 1, 2, 0, 2)      // + third buffer: one stage in flight across the barrier
+    LAB_CASE(143130, 32, 4, 3, 1, 3, 0, 2)      // + e ring of three slabs
+    LAB_CASE(143121, 32, 4, 3, 1, 2, 1, 2)      // + s_setprio 1 around the MFMA groups
+    LAB_CASE_D(143220, 32, 4, 3, 2, 2, 0, 2, 1)      // flags instead of the stage barrier: requests one stage ahead, one buffer of slack
+    LAB_CASE_D(144220, 32, 4, 4, 2, 2, 0, 2, 2)      // flags, four buffers: two stages ahead, one buffer of slack
+    // 64 edges per wave, 4 waves, ONE workgroup per CU (one wave per SIMD, up to 512 registers)
+    LAB_CASE(242020, 64, 4, 2, 0, 2, 0, 1)
+    LAB_CASE(243120, 64, 4, 3, 1, 2, 0, 1)
+    LAB_CASE(244120, 64, 4, 4, 1, 2, 0, 1)
+    LAB_CASE(244130, 64, 4, 4, 1, 3, 0, 1)
+    LAB_CASE(244121, 64, 4, 4, 1, 2, 1, 1)
+    LAB_CASE_D(244220, 64, 4, 4, 2, 2, 0, 1, 2)
+    // 32 edges per wave, 8 waves in ONE workgroup per CU sharing the weight stream (two waves per SIMD in lock step)
+    LAB_CASE(182020, 32, 8, 2, 0, 2, 0, 1)
+    LAB_CASE(183120, 32, 8, 3, 1, 2, 0, 1)
+    LAB_CASE(184120, 32, 8, 4, 1, 2, 0, 1)
+    LAB_CASE(184121, 32, 8, 4, 1, 2, 1, 1)
+    LAB_CASE_D(184220, 32, 8, 4, 2, 2, 0, 1, 2)
+    default: return difusco::set_error(DIFUSCO_EINVAL, "unknown lab variant %d", variant);
+  }
+#undef LAB_CASE
+#undef LAB_CASE_D
+  if (er != hipSuccess) return difusco::set_error(DIFUSCO_EHIP, "lab launch: %s", hipGetErrorString(er));
+  return DIFUSCO_OK;
+}
+}
+#endif  // DIFUSCO_PROFILING

@@ -74,7 +74,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
     const c10::optional<at::Tensor>& perm, const c10::optional<at::Tensor>& row, const c10::optional<at::Tensor>& seg_ptr,
     const c10::optional<at::Tensor>& points, const at::Tensor& xt, double t, c10::ArrayRef<double> post,
     const c10::optional<at::Tensor>& rand, int64_t seed, int64_t offset, at::Tensor workspace, c10::ArrayRef<int64_t> cfg,
-    bool want_pred, bool want_prob, const c10::optional<at::Tensor>& gn_sums) {
+    bool want_pred, bool want_prob, const c10::optional<at::Tensor>& gn_sums, const c10::optional<at::Tensor>& prepared,
+    const c10::optional<at::Tensor>& tbias) {
   TORCH_CHECK(cfg.size() == 9, "cfg = {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}");
   TORCH_CHECK(post.size() <= 8, "post holds at most 8 constants");
   need(weights, at::kFloat, "weights", true);
@@ -130,6 +131,16 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
   a.gn_phase = (int32_t)cfg[7];
   a.flags = (int32_t)cfg[8];
   a.gn_sums = static_cast<double*>(const_cast<void*>(ptr_or_null(gn_sums)));
+  a.prepared = ptr_or_null(prepared);                       // optional prepared state (include/difusco_hip.h, ABI 9)
+  a.tbias = static_cast<const float*>(ptr_or_null(tbias));
+  if (a.tbias) {
+    need(*tbias, at::kFloat, "tbias", true);
+    TORCH_CHECK(tbias->numel() == cfg[0] * cfg[1], "tbias must be [n_layers, hidden]");
+  }
+  if (a.prepared)
+    TORCH_CHECK(prepared->is_cuda() && prepared->is_contiguous() &&
+                    (size_t)prepared->nbytes() >= difusco_prepared_bytes((int)cfg[0], (int)n_nodes),
+                "prepared: contiguous GPU buffer of difusco_prepared_bytes() required");
   check(difusco_denoise_step(&a), "difusco_denoise_step");
   return {xt_out, pred, prob};
 }
@@ -139,9 +150,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
       const c10::optional<at::Tensor>&row, const c10::optional<at::Tensor>&seg_ptr,                                     \
       const c10::optional<at::Tensor>&points, const at::Tensor &xt, double t, c10::ArrayRef<double> post,               \
       const c10::optional<at::Tensor>&rand, int64_t seed, int64_t offset, at::Tensor workspace,                         \
-      c10::ArrayRef<int64_t> cfg, bool want_pred, bool want_prob, const c10::optional<at::Tensor>&gn_sums
-#define STEP_FORWARD \
-  weights, rowptr, col, perm, row, seg_ptr, points, xt, t, post, rand, seed, offset, workspace, cfg, want_pred, want_prob, gn_sums
+      c10::ArrayRef<int64_t> cfg, bool want_pred, bool want_prob, const c10::optional<at::Tensor>&gn_sums,             \
+      const c10::optional<at::Tensor>&prepared, const c10::optional<at::Tensor>&tbias
+#define STEP_FORWARD                                                                                                     \
+  weights, rowptr, col, perm, row, seg_ptr, points, xt, t, post, rand, seed, offset, workspace, cfg, want_pred, want_prob, \
+      gn_sums, prepared, tbias
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> denoise_step_categorical(STEP_SIGNATURE) {
   return step_impl(DIFUSCO_CATEGORICAL, STEP_FORWARD);
@@ -153,7 +166,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> denoise_step_gaussian(STEP_SIGNAT
 const char* kStepSchema =
     "(Tensor weights, Tensor rowptr, Tensor col, Tensor? perm, Tensor? row, Tensor? seg_ptr, Tensor? points, Tensor xt, "
     "float t, float[] post, Tensor? rand, int seed, int offset, Tensor(a!) workspace, int[] cfg, bool want_pred, "
-    "bool want_prob, Tensor(b!)? gn_sums) -> (Tensor, Tensor, Tensor)";
+    "bool want_prob, Tensor(b!)? gn_sums, Tensor? prepared=None, Tensor? tbias=None) -> (Tensor, Tensor, Tensor)";
 
 }  // namespace
 

@@ -53,22 +53,9 @@ def broadcast_weights(state_dict: Optional[dict], device, src: int = 0, group=No
     return (hidden, n_layers, out_channels), buf
 
 
-class BlobEngineConfig(dict):
-    """Minimal stand-in for a state_dict when only the packed blob travelled: carries the three
-    shape keys ``infer_config`` reads."""
-
-    @staticmethod
-    def make(hidden: int, n_layers: int, out_channels: int):
-        return {
-            "node_embed.weight": torch.empty(hidden, 0),
-            f"layers.{n_layers - 1}.U.weight": torch.empty(0),
-            "out.2.weight": torch.empty(out_channels, 0),
-        }
-
-
 def engine_from_broadcast(state_dict: Optional[dict], device, src: int = 0, group=None, precision: str = "fp16x3",
                           fused: bool = True, flags: int = 0):
     from .engine import DenoiseEngine
     (hidden, n_layers, out_channels), blob = broadcast_weights(state_dict, device, src, group)
-    return DenoiseEngine(BlobEngineConfig.make(hidden, n_layers, out_channels), device=device, blob=blob,
-                         precision=precision, fused=fused, flags=flags)
+    return DenoiseEngine(device=device, blob=blob, config=(hidden, n_layers, out_channels), precision=precision, fused=fused,
+                         flags=flags)

@@ -1,6 +1,7 @@
 """The denoise-step engine: owns the packed weights and the workspace on one GPU and drives
 ``difusco_denoise_step`` (C ABI).  PyTorch is used for device memory and streams only."""
 import ctypes
+import os
 from typing import Optional
 
 import numpy as np
@@ -16,17 +17,28 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class DenoiseEngine:
-    def __init__(self, state_dict, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
-                 fused: bool = True, backend: str = "ctypes", flags: int = 0):
+    def __init__(self, state_dict=None, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
+                 fused: bool = True, backend: str = "ctypes", flags: int = 0, config=None):
         """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
-        ``blob``: an already packed blob (e.g. received by RCCL broadcast) instead of packing here."""
+        ``blob`` + ``config=(hidden, n_layers, out_channels)``: an already packed blob (e.g. received by RCCL broadcast)
+        instead of a state_dict to pack here."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.DifuscoHipError("DenoiseEngine needs a GPU device (no CPU fallback exists)")
         _lib.lib()  # fail loudly, now, if the HIP library is missing
-        self.hidden, self.n_layers, self.out_channels = infer_config(state_dict)
+        if config is not None:
+            if blob is None:
+                raise ValueError("config=(hidden, n_layers, out_channels) describes a packed blob: pass blob= as well")
+            self.hidden, self.n_layers, self.out_channels = (int(v) for v in config)
+        else:
+            if state_dict is None:
+                raise ValueError("state_dict, or blob= with config=(hidden, n_layers, out_channels), required")
+            self.hidden, self.n_layers, self.out_channels = infer_config(state_dict)
         if blob is None:
             blob = pack_state_dict(state_dict)
+        _, total = _lib.weights_layout(self.hidden, self.n_layers, self.out_channels)
+        if blob.numel() != total:
+            raise ValueError(f"packed blob has {blob.numel()} floats, the layout of this model has {total}")
         self.blob = blob.to(self.device, dtype=torch.float32).contiguous()
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
@@ -38,8 +50,17 @@ class DenoiseEngine:
         self.backend = backend
         if backend == "torch":
             from . import torch_ops
+            from .build import LIB_PATH
+            # libdifusco_torch.so is linked against the PRODUCTION library: with the profiling build (or another
+            # DIFUSCO_HIP_LIBRARY) behind ctypes, the debug knobs / profiler state set through ctypes would not apply to
+            # steps issued through torch.ops - an A/B taken that way would silently measure the production kernels
+            if os.path.realpath(_lib.loaded_path()) != os.path.realpath(LIB_PATH):
+                raise _lib.DifuscoHipError(
+                    f"backend='torch' launches through {LIB_PATH}, but ctypes loaded {_lib.loaded_path()}: "
+                    "use backend='ctypes' with the profiling library / DIFUSCO_HIP_LIBRARY")
             self._ops = torch_ops.load()
         self._ws = None
+        self._tbias = {}            # t -> [n_layers, hidden] time-bias rows on the device (prepare_times / lazily per t)
         self.calls = 0
 
     # ---- workspace -----------------------------------------------------------------------------
@@ -52,11 +73,58 @@ class DenoiseEngine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    # ---- prepared state (difusco_step_args.prepared / .tbias) --------------------------------------
+    def prepare_times(self, ts) -> None:
+        """Time-bias rows of every diffusion time in ``ts`` (e.g. the 50 steps of a schedule) in ONE launch; ``step`` then
+        passes the row block of its ``t`` instead of running the time MLP (``gnn_encoder.py:396,329-337``)."""
+        todo = sorted({float(t) for t in ts} - set(self._tbias))
+        if not todo:
+            return
+        out = torch.empty((len(todo), self.n_layers, self.hidden), dtype=torch.float32, device=self.device)
+        arr = (ctypes.c_float * len(todo))(*todo)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().difusco_time_bias_rows(
+                self.hidden, self.n_layers, self.out_channels, _ptr(self.blob), arr, len(todo), _ptr(out),
+                ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        if len(self._tbias) > 4096:
+            self._tbias.clear()
+        for i, t in enumerate(todo):
+            self._tbias[t] = out[i]
+
+    def prepare(self, g: CsrGraph, points: torch.Tensor) -> Optional[torch.Tensor]:
+        """The step-invariant part of a TSP step for (these weights, this graph, these coordinates) - node embedding,
+        layer 0's node linear, the two-row edge-input table (``difusco_prepare``) - as an opaque device buffer to hand to
+        ``step(prepared=...)``.  None when the fused path does not apply (the step then computes everything itself)."""
+        if not (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_segments == 1
+                and g.n_edges > 0):
+            return None
+        pts = points.to(self.device, dtype=torch.float32).contiguous()
+        if pts.numel() != 2 * g.n_nodes:
+            raise ValueError("points must be [n_nodes, 2]")
+        if g.node_order is not None:
+            pts = pts.reshape(-1, 2).index_select(0, g.node_order)
+        need = _lib.lib().difusco_prepared_bytes(self.hidden, g.n_nodes)
+        buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._workspace(g)
+        a = _lib.StepArgs()
+        a.struct_size = ctypes.sizeof(_lib.StepArgs)
+        a.abi_version = _lib.ABI_VERSION
+        a.hidden, a.n_layers, a.out_channels, a.task = self.hidden, self.n_layers, self.out_channels, _lib.TASK_TSP
+        a.weights = _ptr(self.blob)
+        a.n_nodes, a.n_edges, a.n_segments = g.n_nodes, g.n_edges, 1
+        a.points = _ptr(pts)
+        a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
+        a.stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        a.precision = _lib.PRECISIONS[self.precision]
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().difusco_prepare(ctypes.byref(a), _ptr(buf), buf.numel()))
+        return buf
+
     # ---- one step ------------------------------------------------------------------------------
     def step(self, g: CsrGraph, task: int, diffusion: int, xt: torch.Tensor, t: float, post: np.ndarray,
              points: Optional[torch.Tensor] = None, xt_is_binary: bool = False,
              rand: Optional[torch.Tensor] = None, seed: int = 0, offset: int = 0,
-             want_pred: bool = False, want_prob: bool = False, gn_reduce=None):
+             want_pred: bool = False, want_prob: bool = False, gn_reduce=None, prepared: Optional[torch.Tensor] = None):
         """xt: fp32, TSP [E] in caller edge order / MIS [N].  Returns (xt_next, pred|None, prob|None);
         asynchronous on the current stream.
 
@@ -64,12 +132,18 @@ class DenoiseEngine:
         GroupNorm input over THIS call's rows + the row count) and adding the other shards' values in place - e.g.
         ``lambda t: torch.distributed.all_reduce(t)``.  The step then runs in two phases around it, which makes a
         batch sharded over several GPUs use the statistics of the whole batch, like the reference's single call over
-        all graphs (SURVEY 8(e) "global statistics").  Without it the statistics are those of this call."""
+        all graphs (SURVEY 8(e) "global statistics").  Without it the statistics are those of this call.
+
+        ``prepared``: the buffer ``prepare(g, points)`` returned for this graph and these coordinates (TSP): the step skips
+        what it holds; ``points`` may then be omitted.  The time-bias rows of ``t`` are taken from the ``prepare_times``
+        cache when present.  Both are bit-identical to the stateless step."""
         dev = self.device
         xt = xt.to(dev, dtype=torch.float32).contiguous().reshape(-1)
         rows = g.n_edges if task == _lib.TASK_TSP else g.n_nodes
         if xt.numel() != rows:
             raise ValueError(f"xt has {xt.numel()} elements, the graph has {rows} output rows")
+        if prepared is not None and task == _lib.TASK_TSP:
+            points = None      # (h0 and layer 0's node rows come from the prepared buffer)
         if points is not None:
             points = points.to(dev, dtype=torch.float32).contiguous()
             if points.numel() != 2 * g.n_nodes:
@@ -86,11 +160,12 @@ class DenoiseEngine:
         pred = torch.empty((rows, 2) if C == 2 else (rows,), dtype=torch.float32, device=dev) if want_pred else None
         prob = torch.empty(rows, dtype=torch.float32, device=dev) if (want_prob and C == 2) else None
         ws = self._workspace(g)
+        tbias = self._tbias.get(float(t))
         # the Philox key and offset are 63-bit on both backends (the torch op schema carries signed 64-bit ints)
         seed, offset = int(seed) & (2 ** 63 - 1), int(offset) & (2 ** 63 - 1)
         if self.backend == "torch":
             return self._step_torch_op(g, task, diffusion, xt, t, post, points, xt_is_binary, rand, seed, offset,
-                                       want_pred, want_prob, gn_reduce, ws)
+                                       want_pred, want_prob, gn_reduce, ws, prepared, tbias)
 
         a = _lib.StepArgs()
         a.struct_size = ctypes.sizeof(_lib.StepArgs)
@@ -117,6 +192,7 @@ class DenoiseEngine:
         a.row = _ptr(g.row)
         a.gn_phase, a.gn_sums = 0, None
         a.flags = self.flags
+        a.prepared, a.tbias = _ptr(prepared), _ptr(tbias)
         with torch.cuda.device(dev):
             if gn_reduce is None:
                 _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))
@@ -134,7 +210,7 @@ class DenoiseEngine:
         return xt_out, pred, prob
 
     def _step_torch_op(self, g, task, diffusion, xt, t, post, points, xt_is_binary, rand, seed, offset, want_pred,
-                       want_prob, gn_reduce, ws):
+                       want_prob, gn_reduce, ws, prepared=None, tbias=None):
         """The same step through ``torch.ops.difusco.denoise_step_{categorical,gaussian}`` (csrc/torch_ops.cpp)."""
         op = self._ops.denoise_step_categorical if diffusion == _lib.CATEGORICAL else self._ops.denoise_step_gaussian
         cfg = [self.hidden, self.n_layers, self.out_channels, task, _lib.PRECISIONS[self.precision], 0 if self.fused else 1,
@@ -145,7 +221,7 @@ class DenoiseEngine:
         def call(phase, sums):
             cfg[7] = phase
             return op(self.blob, g.rowptr, g.col, g.perm, g.row, seg, points, xt, float(t), post, rand, seed, offset, ws, cfg,
-                      want_pred, want_prob, sums)
+                      want_pred, want_prob, sums, prepared, tbias)
         if gn_reduce is None:
             out = call(0, None)
         else:

@@ -44,7 +44,8 @@ class COMetaModel:
 
     def __init__(self, param_args=None, state_dict=None, node_feature_only=False, device="cuda:0",
                  seed: Optional[int] = None, engine: Optional[DenoiseEngine] = None, precision: str = "fp16x3",
-                 fused: bool = True, gn_reduce=None, reorder_nodes: bool = True, backend: str = "ctypes", flags: int = 0):
+                 fused: bool = True, gn_reduce=None, reorder_nodes: bool = True, backend: str = "ctypes", flags: int = 0,
+                 prepare: bool = True, strict_binary_check: bool = False):
         args = dict(_DEFAULTS)
         if param_args is not None:
             args.update(vars(param_args) if not isinstance(param_args, dict) else param_args)
@@ -83,6 +84,13 @@ class COMetaModel:
         self.seed = int(seed) & (2 ** 63 - 1)
         self._binary_out = None     # (tensor, version) of the last Bernoulli-sampled output: known to be exactly {0,1}
         self._graph_cache = {}
+        # prepared state (difusco_step_args.prepared / .tbias): what a TSP step computes from (weights, graph, points) alone
+        # is computed once per (graph, points) and reused by every step of a sampling loop; `prepare=False` = stateless steps
+        self.prepare = bool(prepare)
+        self._prep_cache = {}
+        # always verify on the device that a categorical x_t is exactly {0,1} (one reduction + sync per step) instead of
+        # trusting the identity of our own last Bernoulli output - see _xt_is_binary
+        self.strict_binary_check = bool(strict_binary_check)
         self.reorder_nodes = reorder_nodes      # TSP: Morton-order the nodes of every graph for L2 locality (graph.py)
         # optional: shard-summing callable for the head GroupNorm statistics (difusco_amd.dist.gn_allreduce); None =
         # statistics of each call's own rows, the reference's behaviour for that call
@@ -114,6 +122,27 @@ class COMetaModel:
             self._graph_cache[key] = g
         return g[0]
 
+    def _prepared(self, g: CsrGraph, points):
+        """Prepared buffer of (this engine, graph ``g``, ``points``) or None; cached on the identity of ``points`` (the
+        sampling loop passes the same tensor 50 times - same rule as ``prepare_graph``)."""
+        if not self.prepare or points is None:
+            return None
+        version = 0 if points.is_inference() else points._version
+        key = (id(g), points.data_ptr(), tuple(points.shape), version)
+        hit = self._prep_cache.get(key)
+        if hit is None:
+            if len(self._prep_cache) > 8:
+                self._prep_cache.clear()
+            hit = (self.model.prepare(g, points), g, points)      # keep g / points alive: id() and data_ptr() stay unique
+            self._prep_cache[key] = hit
+        return hit[0]
+
+    def prepare_schedule(self, times) -> None:
+        """Precompute the time-bias rows of every diffusion time a sampling loop will visit (one launch; ``sample`` calls it
+        with the schedule's ``t1`` values).  Steps at other times run the time MLP themselves."""
+        if self.prepare:
+            self.model.prepare_times([_as_int(t) for t in times])
+
     def duplicate_edge_index(self, edge_index, num_nodes, device):
         """Disjoint union of ``parallel_sampling`` replicas (pl_meta_model.py:177-184)."""
         P = self.args.parallel_sampling
@@ -130,7 +159,10 @@ class COMetaModel:
         table and the table-input first layer are exact only for 0/1 inputs.  The sampling loop feeds our own Bernoulli
         outputs back, which are known without looking (same storage, unmodified); anything else is checked on the
         device (one small reduction + sync per call).  Values whose truncation is not 0/1 raise, like ``one_hot``."""
-        known = self._binary_out      # (tensor kept alive, version or None): the storage address is unique while held
+        # NOTE (tensors without a version counter, i.e. created under torch.inference_mode()): an in-place edit of the tensor
+        # this model returned cannot be detected without looking at the data; such an x_t must not be mutated in place
+        # between steps (or construct the model with strict_binary_check=True, which always looks).
+        known = None if getattr(self, "strict_binary_check", False) else self._binary_out      # (tensor kept alive, version or None)
         if known is not None and known[0].data_ptr() == xt.data_ptr() and known[0].numel() == xt.numel() \
                 and (known[1] is None) == xt.is_inference() and (known[1] is None or known[1] == xt._version):
             return True
@@ -152,7 +184,8 @@ class COMetaModel:
         out, pred, prob = self.model.step(
             g, task, _lib.CATEGORICAL, xt, float(t), post, points=points, xt_is_binary=self._xt_is_binary(xt),
             rand=uniform if target_t > 0 else None, seed=self.seed, offset=self._next_offset(),
-            want_pred=return_aux, want_prob=return_aux, gn_reduce=self.gn_reduce)
+            want_pred=return_aux, want_prob=return_aux, gn_reduce=self.gn_reduce,
+            prepared=self._prepared(g, points) if task == _lib.TASK_TSP else None)
         # tensors created under torch.inference_mode() (Lightning's default for trainer.test) have no version counter:
         # for those the held reference + storage identity is the whole key (no host sync in the 50-step loop either way)
         self._binary_out = (out, None if out.is_inference() else out._version) if target_t > 0 else None
@@ -167,7 +200,7 @@ class COMetaModel:
         out, pred, _ = self.model.step(
             g, task, _lib.GAUSSIAN, xt, float(t), post, points=points, xt_is_binary=False,
             rand=noise if post[4] != 0 else None, seed=self.seed, offset=self._next_offset(), want_pred=return_aux,
-            gn_reduce=self.gn_reduce)
+            gn_reduce=self.gn_reduce, prepared=self._prepared(g, points) if task == _lib.TASK_TSP else None)
         return (out, pred) if return_aux else out
 
 
@@ -221,6 +254,7 @@ class TSPModel(COMetaModel):
         xt = xt0.to(self.device)
         if self.diffusion_type == "categorical":
             xt = (xt > 0).float()
+        self.prepare_schedule([sched(i)[0] for i in range(steps)])
         for i in range(steps):
             t1, t2 = sched(i)
             t1, t2 = np.array([t1]).astype(int), np.array([t2]).astype(int)
@@ -256,6 +290,7 @@ class MISModel(COMetaModel):
         xt = xt0.to(self.device)
         if self.diffusion_type == "categorical":
             xt = (xt > 0).float()
+        self.prepare_schedule([sched(i)[0] for i in range(steps)])
         for i in range(steps):
             t1, t2 = sched(i)
             t1, t2 = np.array([t1]).astype(int), np.array([t2]).astype(int)

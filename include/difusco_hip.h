@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 8
+#define DIFUSCO_ABI_VERSION 9
 
 enum {
   DIFUSCO_OK = 0,
@@ -181,6 +181,18 @@ typedef struct difusco_step_args {
   int32_t gn_phase;
   int32_t flags;          /* DIFUSCO_FLAG_*: per-call A/B switches of the fused path (results equal to rounding) */
   double* gn_sums;
+  /* Optional PREPARED STATE (ABI 9).  Both NULL = the stateless step: everything is computed from the arguments above.
+   * A sampling loop calls the step 50 times with the same weights, graph and coordinates (pl_tsp_model.py:207-217); what
+   * does not depend on x_t or t is then computed ONCE and handed back in:
+   *   prepared  (TSP, fused path): the buffer difusco_prepare() filled for THIS (weights, precision, graph, points): the
+   *             node embedding h0 = node_embed(pos_embed(points)) (gnn_encoder.py:394), layer 0's U|V|A|B rows of it and the
+   *             two-row edge-input table of a categorical step - the step then skips those launches.  Ignored on the
+   *             unfused path and for MIS (whose h0 is the embedding of x_t).
+   *   tbias     [n_layers, hidden] time-bias rows of THIS t (difusco_time_bias_rows(); gnn_encoder.py:396,329-337,442) - the
+   *             step skips the time MLP.
+   * Same kernels, same operands: a step with prepared state is bit-identical to the stateless one (GPU test). */
+  const void* prepared;
+  const float* tbias;
 } difusco_step_args;
 
 enum {
@@ -194,6 +206,17 @@ enum {
 };
 
 size_t difusco_workspace_bytes(int hidden, int n_layers, int n_nodes, int n_edges, int n_segments);
+
+/* ---- prepared state (optional, see difusco_step_args.prepared / .tbias) -------------------------------------------
+ * difusco_prepared_bytes(): size of the buffer for a call shape.  difusco_prepare(): fills it from args->{hidden, n_layers,
+ * out_channels, task (TSP), weights, precision, n_nodes, n_edges, points, workspace, stream} - the graph arrays, x_t and
+ * the outputs are not read.  `points` must be in the node numbering of the graph arrays the later steps pass.
+ * difusco_time_bias_rows(): out[i] = the [n_layers, hidden] rows of t_host[i] (HOST array, n_t values), DEVICE
+ * out [n_t, n_layers, hidden]; one launch per 64 values.  All asynchronous on the stream. */
+size_t difusco_prepared_bytes(int hidden, int n_nodes);
+int difusco_prepare(const difusco_step_args* args, void* prepared, size_t prepared_bytes);
+int difusco_time_bias_rows(int hidden, int n_layers, int out_channels, const float* weights, const float* t_host, int n_t,
+                           float* out, void* stream);
 
 /* One reverse-diffusion step: GNN denoiser forward + posterior (+ sample).  Asynchronous on
  * args->stream.  Replaces {categorical,gaussian}_denoise_step of pl_tsp_model.py / pl_mis_model.py. */
@@ -336,10 +359,19 @@ int difusco_profile_collect(double* ms, int64_t* launches, int n_categories);
  * key 0: compile-time ablation mask (bit0 skip neighbour-table gathers, bit1 skip the neighbour sum, bit2 skip
  *        LN/activation math, bit3 skip GEMM 2, 16 = production code + phase stamps ...): results are WRONG by design;
  * key 6: extra dynamic LDS bytes (occupancy probe);  key 7: A/B variant of the scheduling options (OPT bits);
- * key 8: k steps of load lookahead in the node-row linear (1 or 4). */
+ * key 8: k steps of load lookahead in the node-row linear (0, 1 or 4);  key 9: start delay (cycles) of the second-slot workgroups of
+ *        the fused kernel's first dispatch generation (experiment of round 3);  key 10: timing-only ablation mask of the node-row
+ *        linear (node_linear.hip, 0..31). */
 int difusco_debug_set(int key, int value);
 /* key 1: device buffer [n_tiles][16] of uint64 receiving s_memtime stamps of the fused kernel's phases (NULL disables) */
 int difusco_debug_set_ptr(int key, void* p);
+/* Stage-loop laboratory (csrc/stage_lab.hip): GEMM 1 of the fused edge layer alone - out = C e on the tiled e stream
+ * (fp16 hi | lo planes of C, 3 MFMA products, weight stages through LDS by LDS-DMA) - in the workgroup geometry /
+ * synchronisation scheme `variant` names (EPW/32 * 100000 + WAVES * 10000 + NBUF * 1000 + SYNC * 100 + RING * 10 + PRIO).
+ * e / out: DEVICE, tiled [n_edges, 256] (n_edges a multiple of the variant's edges per workgroup); inv_c = 2^-kc of the
+ * planes; do_store 0 = timing only; lds_pad = extra dynamic LDS bytes.  scripts/bench_stage_lab.py drives it. */
+int difusco_lab_gemm1(int variant, const float* e, const void* planes, float* out, int n_edges, float inv_c, int do_store,
+                      int lds_pad, void* stream);
 #endif
 
 #ifdef __cplusplus

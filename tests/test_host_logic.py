@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/difusco_hip.h but not exported"
     assert L.difusco_abi_version() == _lib.ABI_VERSION
     # the profiling knobs (process-wide state, timing-only kernel variants) live in libdifusco_hip_prof.so only
-    assert prof_names == {"difusco_debug_set", "difusco_debug_set_ptr"}
+    assert prof_names == {"difusco_debug_set", "difusco_debug_set_ptr", "difusco_lab_gemm1"}
     for n in prof_names:
         assert not hasattr(L, n), f"{n} must not be exported by the production library"
 
@@ -479,6 +479,12 @@ def test_binary_input_detection_on_host():
             torch.Tensor.all = lambda self, *a, **k: (seen.append(1), orig_all(self, *a, **k))[1]
             assert m._xt_is_binary(out_i) is True
             assert not seen, "the known-binary fast path must not inspect the tensor"
+            # an in-place edit of an inference tensor is invisible to that key; strict_binary_check=True looks
+            m.strict_binary_check = True
+            out_i_bad = torch.tensor([0.5, 0.0, 1.0])
+            m._binary_out = (out_i_bad, None)
+            assert m._xt_is_binary(out_i_bad) is False and seen
+            m.strict_binary_check = False
             assert m._xt_is_binary(torch.tensor([1.0, 0.0, 1.0])) is True and seen     # a different tensor is looked at
         finally:
             torch.Tensor.all = orig_all
