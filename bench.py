@@ -281,7 +281,7 @@ def main():
             for name in ("tsp500", "tsp10000", "mis"):
                 t0 = time.perf_counter()
                 sub = measure(args, name, args.sub_steps, 2, 1, False, rank, world, device, dry, step_flags, dist, overrides=False)
-                keep = {k: sub[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config") if k in sub}
+                keep = {k: sub[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "repeats") if k in sub}
                 for k in ("roofline", "cpu_baseline", "parity_linf"):
                     if k in sub:
                         keep[k] = sub[k]
@@ -310,6 +310,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
     from difusco_amd.schedules import InferenceSchedule
     from difusco_amd.synthetic import er_mis_edge_index, random_state_dict, tsp_batch_gpu
 
+    broadcast_ms = None
     # frozen weights: rank 0 creates, RCCL broadcast of the packed blob over xGMI
     params = random_state_dict(H, LAYERS, 1 if gaussian else 2, seed=20240926) if rank == 0 or world == 1 else None
     if dry:
@@ -319,10 +320,19 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
             assert (h_, l_, c_) == (H, LAYERS, 1 if gaussian else 2) and blob.numel() > 0 and bool(torch.isfinite(blob).all())
         engine = None
     elif world > 1:
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        tb0 = time.perf_counter()
         engine = engine_from_broadcast(params, device, src=0, precision=args.precision, fused=not args.no_fusion,
                                        flags=step_flags)
+        torch.cuda.synchronize(device)
+        broadcast_ms = 1e3 * (time.perf_counter() - tb0)      # rank-0 packing + the RCCL broadcast of the blob
+        if args.backend != "ctypes":
+            engine = DenoiseEngine(device=device, blob=engine.blob, config=(engine.hidden, engine.n_layers, engine.out_channels),
+                                   precision=args.precision, fused=not args.no_fusion, flags=step_flags, backend=args.backend)
     else:
-        engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion, flags=step_flags)
+        engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion, flags=step_flags,
+                               backend=args.backend)
     margs = dict(diffusion_type=wl["diffusion"], diffusion_schedule="linear", diffusion_steps=1000,
                  inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=knn if not mis else -1,
                  n_layers=LAYERS, hidden_dim=H, inference_trick="ddim")
@@ -342,7 +352,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         model = _PlumbingModel()
     else:
         model = (MISModel if mis else TSPModel)(margs, engine=engine, seed=1234 + rank, gn_reduce=gn_reduce,
-                                                reorder_nodes=not args.no_node_reorder)
+                                                reorder_nodes=not args.no_node_reorder, prepare=not args.no_prepare)
 
     # this rank's shard of the global batch (weak scaling: graphs_per_gpu fixed)
     G_total = graphs_per_gpu * world
@@ -390,7 +400,8 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         for k in range(args.streams):
             eng_k = DenoiseEngine(params, device=device, blob=engine.blob, precision=args.precision, fused=not args.no_fusion,
                                   flags=step_flags)
-            m_k = TSPModel(margs, engine=eng_k, seed=1234 + rank + 100 * k, reorder_nodes=not args.no_node_reorder)
+            m_k = TSPModel(margs, engine=eng_k, seed=1234 + rank + 100 * k, reorder_nodes=not args.no_node_reorder,
+                           prepare=not args.no_prepare)
             p_k, e_k = tsp_batch_gpu(nodes, knn, range(lo + k * per, lo + (k + 1) * per), device)
             x_k = torch.randn(e_k.shape[1], generator=gen)
             x_k = (x_k if gaussian else (x_k > 0).float()).to(device)
@@ -418,21 +429,50 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         if not dry:
             torch.cuda.synchronize(device)
 
+    # per-sampling-run preparation, as TSPModel.sample / MISModel.sample do at entry: the time-bias rows of the 50 schedule steps
+    # in one launch; the graph's step-invariant state (TSP) is built by the first warm-up step and reused.  Timed separately:
+    # it happens once per 50-step run, the timed region below is `steps` steps of that run (pl_tsp_model.py:207-217).
+    prepare_ms = None
+    if not dry:
+        torch.cuda.synchronize(device)
+        tp0 = time.perf_counter()
+        for mdl in ([model] if groups is None else [gk["model"] for gk in groups]):
+            mdl.prepare_schedule([sched(i)[0] for i in range(50)])
+        torch.cuda.synchronize(device)
+        prepare_ms = 1e3 * (time.perf_counter() - tp0)
     for i in range(warmup):
         xt = one_step(i, xt)
     NCAT = 5
+    repeats = max(1, args.repeats)
     if not args.no_profile:
-        _lib.check(_lib.lib().difusco_profile_enable(1 if args.profile_all else 2, steps * (4 * LAYERS + 16)))
-    fence()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        xt = one_step(warmup + i, xt)
-    fence()
-    dt = time.perf_counter() - t0
+        _lib.check(_lib.lib().difusco_profile_enable(1 if args.profile_all else 2, repeats * steps * (4 * LAYERS + 16)))
+    rep_dt, rep_enq, rep_local = [], [], []
+    for rep in range(repeats):      # every repetition: exactly `steps` steps between two fences, max over ranks
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            xt = one_step(warmup + rep * steps + i, xt)
+        t_enq = time.perf_counter() - t0      # host time to enqueue the steps (binding + launch overhead; the GPU runs behind)
+        fence()
+        dt_r = time.perf_counter() - t0
+        rep_local.append(dt_r)
+        if world > 1:
+            tmax = torch.tensor([dt_r], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_r = float(tmax.item())
+        rep_dt.append(dt_r)
+        rep_enq.append(t_enq)
+    # the reported region is the MEDIAN repetition (one K-step loop between fences); all repetitions are listed
+    order = sorted(range(repeats), key=lambda k: rep_dt[k])
+    dt = rep_dt[order[(repeats - 1) // 2]]
+    # evidence that RCCL saw every rank: world size and the per-rank loop times, all-gathered
+    ranks_seen, rank_ms = 1, [1e3 * dt / steps]
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([float(rank), 1e3 * rep_local[order[(repeats - 1) // 2]] / steps], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks_seen = len({int(v[0].item()) for v in allr})
+        rank_ms = [float(v[1].item()) for v in allr]
 
     prof = None
     if not args.no_profile:
@@ -450,7 +490,17 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
                 f"TSP-{nodes} k-NN sparse {wl['diffusion']}"),
             "value": value, "unit": "graph-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", **({"dry_run": True} if dry else {}),
+            "vs_baseline": None,
+            "dtype": {"fp16x3": "f32 (fp16x3 split MFMA, fp32 accumulate)", "bf16x3": "f32 (bf16x3 split MFMA, fp32 accumulate)",
+                      "bf16x6": "f32 (bf16x6 split MFMA, fp32 accumulate)", "fp32": "f32 (fp32 MFMA)"}[args.precision],
+            "data": "synthetic", **({"dry_run": True} if dry else {}),
+            "repeats": {"n": repeats, "reported": "median repetition (each = `steps` steps between two fences, max over ranks)",
+                        "ms_per_step": [1e3 * d / steps for d in rep_dt], "min_ms_per_step": 1e3 * min(rep_dt) / steps,
+                        "median_ms_per_step": 1e3 * dt / steps, "max_ms_per_step": 1e3 * max(rep_dt) / steps,
+                        "value_min": G_total * steps / max(rep_dt), "value_max": G_total * steps / min(rep_dt)},
+            "host_enqueue_us_per_step": 1e6 * sorted(rep_enq)[(repeats - 1) // 2] / steps,
+            "prepare_ms_per_sampling_run": prepare_ms,
+            "ranks_seen": ranks_seen, "rank_ms_per_step": rank_ms, "broadcast_ms": broadcast_ms,
             "config": {"workload": (f"MIS Erdos-Renyi n~U[700,800] p=0.15 (+reverse edges, +self loops) sparse categorical"
                                     if mis else f"TSP-{nodes} k-NN K={knn} sparse {wl['diffusion']}") +
                                    f", cosine 50-step schedule, {graphs_per_gpu} graphs per GPU "
@@ -461,7 +511,9 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
                        "rng": "on-device philox", "weights_seed": 20240926, "edge_linear_arithmetic": args.precision,
                        "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3"),
                        "node_order": "caller" if (args.no_node_reorder or mis) else "morton per graph (graph.py)",
-                       "fused_opt": args.fused_opt, "debug_set": args.debug_set or None, "streams": args.streams},
+                       "fused_opt": args.fused_opt, "debug_set": args.debug_set or None, "streams": args.streams,
+                       "binding": ("ctypes -> C ABI" if args.backend == "ctypes" else "torch.ops.difusco.* custom ops -> C ABI"),
+                       "prepared_state": (not args.no_prepare)},
         }
         if prof is not None and prof["launches"][0] > 0:
             n_lin = prof["launches"][0]
@@ -489,26 +541,32 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
                      f"linear_rows_split_kernel<256,256,{3 if args.precision == 'bf16x6' else 2},"
                      f"{'Fp16' if args.precision == 'fp16x3' else 'Bf16'}> "
                      f"(E-row linear, fp32 split into 16-bit planes, {n_prod} MFMA products)")
-            if mfma_tf / mfma_peak >= hbm_gbs / PEAK_HBM_GBS:
-                out["roofline"] = {"bound": "mfma", "achieved": mfma_tf, "peak": mfma_peak, "unit": "TFLOP/s",
-                                   "frac": mfma_tf / mfma_peak, "traffic": None}
+            # Headline fraction = ALGORITHMIC work / time / peak: every fp32 multiply-add of the two E-row GEMMs
+            # counted ONCE against the dense 16-bit MFMA peak.  The matrix cores actually execute n_prod 16-bit products per
+            # fp32 product (split precision): that is `frac_issued` (= the pipe occupancy the PMC pass reports as `pipe_busy`).
+            alg_tf = flops / avg_s / 1e12
+            variant = ("fused" if fused else "unfused") + "-" + args.precision
+            bound = "mfma" if mfma_tf / mfma_peak >= hbm_gbs / PEAK_HBM_GBS else "hbm"
+            traffic = pmc_traffic_bytes(kname, workload, E_local, variant)
+            if bound == "mfma":
+                out["roofline"] = {"bound": "mfma", "achieved": alg_tf, "peak": mfma_peak, "unit": "TFLOP/s",
+                                   "frac": alg_tf / mfma_peak, "traffic": traffic}
             else:
                 out["roofline"] = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": None}
-            variant = ("fused" if fused else "unfused") + "-" + args.precision
-            out["roofline"]["traffic"] = pmc_traffic_bytes(kname, workload, E_local, variant)
-            # "achieved" / "frac" count the matrix work ISSUED (every fp32 product is carried by n_prod 16-bit MFMA
-            # products); frac_algorithmic counts each algorithmic flop once against the same peak, and
-            # frac_fp32_mfma_peak against the exact-fp32 MFMA peak (what the arithmetic would cost unsplit)
+                                   "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": traffic}
             out["roofline"].update({"kernel": kname, "avg_launch_ms": avg_s * 1e3, "launches": n_lin,
+                                    "bound_note": "the kernel issues n_prod x the algorithmic flops on the matrix cores: by ISSUED work "
+                                                  "it sits nearer the MFMA roof than the HBM roof, hence bound = mfma; frac counts "
+                                                  "each algorithmic flop once",
                                     "algorithmic_flops_per_launch": flops, "mfma_products": n_prod,
                                     "algorithmic_bytes_per_launch": bytes_alg,
-                                    "mfma_TFLOPs_issued": mfma_tf, "mfma_peak_TFLOPs": mfma_peak,
-                                    "algorithmic_TFLOPs": flops / avg_s / 1e12,
-                                    "frac_algorithmic": flops / avg_s / 1e12 / mfma_peak,
-                                    "frac_fp32_mfma_peak": flops / avg_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                    "algorithmic_TFLOPs": alg_tf, "mfma_peak_TFLOPs": mfma_peak,
+                                    "frac_algorithmic": alg_tf / mfma_peak,
+                                    "mfma_TFLOPs_issued": mfma_tf, "frac_issued": mfma_tf / mfma_peak,
+                                    "pipe_busy": pmc_pipe_busy(workload, E_local, variant, avg_s),
+                                    "frac_fp32_mfma_peak": alg_tf / PEAK_FP32_MFMA_TFLOPS,
                                     "hbm_GBs_algorithmic": hbm_gbs, "hbm_frac_of_8TBs": hbm_gbs / PEAK_HBM_GBS,
-                                    "other_ms_per_step": 1e3 * dt / steps - avg_s * 1e3 * n_lin / steps})
+                                    "other_ms_per_step": 1e3 * dt / steps - avg_s * 1e3 * n_lin / (steps * repeats)})
             n_g = max(prof["launches"][2], 1)
             g_s = prof["ms"][2] / n_g * 1e-3
             if fused:
@@ -534,7 +592,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
             out["kernels"].update({
                 "head": {"ms_total": prof["ms"][3], "launches": prof["launches"][3]},
                 "embed_misc": {"ms_total": prof["ms"][4], "launches": prof["launches"][4]},
-                "sum_ms_per_step": sum(prof["ms"]) / steps,
+                "sum_ms_per_step": sum(prof["ms"]) / (steps * repeats),
             })
         if world == 1 and exact_fp32 and args.precision != "fp32":
             # the same workload with every E-row contraction on v_mfma_f32_32x32x2_f32 (exact fp32, no split planes):

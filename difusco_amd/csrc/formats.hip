@@ -392,7 +392,7 @@ int difusco_mcts_heatmap_prepare(int n_nodes, int64_t n_edges, const int32_t* ro
       if (k_req > positives)
         return set_error(DIFUSCO_EINVAL, "mcts_heatmap: fewer positive entries (%lld) than expected_valid_value_num (%lld); "
                          "the reference raises IndexError here", positives, k_req);
-      if (positives == 0) return set_error(DIFUSCO_EINVAL, "mcts_heatmap: no positive entry");
+      if (positives == 0) return set_error(DIFUSCO_EINVAL, "mcts_heatmap: IndexError: no positive entry (the reference indexes an empty valid_values array here)");
       // k == 0: the reference takes valid_values[-0] = valid_values[0], the SMALLEST positive value
       rank = k_req > 0 ? k_req : positives;
     }

@@ -136,6 +136,8 @@ def _threshold_and_top3(sp: _SparseHeat, pts, k: int, block_rows: int, dtype):
     for lo, hi, v in blocks():
         top3[lo:hi] = np.argsort(v, axis=1)[:, -3:]
         hist += np.bincount(v[v > 0.0].view(np.uint32) >> 16, minlength=1 << 16)
+    if hist.sum() == 0:
+        raise IndexError("no positive entry")            # the reference indexes an empty valid_values array here (k = 0 too)
     if k > hist.sum():
         raise IndexError("fewer positive entries than expected_valid_value_num")     # the reference fails here as well
     if k == 0:                                    # valid_values[-0] is valid_values[0]: the SMALLEST positive value
@@ -287,8 +289,13 @@ def write_mcts_heatmap(heat=None, points=None, num_nodes: int = None, output_dir
                        block_rows: Optional[int] = None, use_gpu: Optional[bool] = None, adj_matrix=None) -> str:
     """File name and directory layout of convert_numpy_to_txt.py:60-66; rows are streamed to the file.  ``heat`` (alias
     ``adj_matrix``, the reference's name for the dense input) is either a dense [N,N] array (``edge_index`` None) or the
-    sparse [E] heatmap on ``edge_index`` [2,E] - numpy arrays or torch tensors.  ``use_gpu``: None = the GPU kernels when a
-    GPU is present and the values are float32 (csrc/formats.hip), the host numpy sweeps otherwise; both give the same text."""
+    sparse [E] heatmap on ``edge_index`` [2,E] - numpy arrays or torch tensors.
+
+    ``use_gpu``: None / True = the GPU kernels (csrc/formats.hip), which compute in float32 like the reference's own data
+    flow (``pl_tsp_model.py:258-267`` dumps float32 heatmaps and float32 coordinates): inputs of any other dtype are cast to
+    float32 ON THE DEVICE, and a host without a GPU raises - nothing drops to the host silently (at N = 10^4 the host
+    sweeps take 31 s against 2.8 ms).  ``use_gpu=False``, explicitly: the host numpy sweeps in the dtype of the inputs
+    (float64 arithmetic for float64 inputs; GPU-less hosts and the CPU test-suite use this); same text for float32 inputs."""
     if heat is None:
         heat = adj_matrix
     if heat is None or points is None or num_nodes is None or output_dir is None:
@@ -297,10 +304,11 @@ def write_mcts_heatmap(heat=None, points=None, num_nodes: int = None, output_dir
     def host(x):
         return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
-    def is_f32(x):
-        return str(getattr(x, "dtype", "")).replace("torch.", "") == "float32"
     if use_gpu is None:
-        use_gpu = _gpu_available() and is_f32(heat) and is_f32(points)
+        use_gpu = True
+    if use_gpu and not _gpu_available():
+        from . import _lib
+        raise _lib.DifuscoHipError("write_mcts_heatmap: no GPU is visible; pass use_gpu=False for the host numpy program")
     folder = f"{output_dir}/{heatmap_prefix}/tsp{num_nodes}"
     os.makedirs(folder, exist_ok=True)
     path = f"{folder}/heatmaptsp{num_nodes}_{index}.txt"

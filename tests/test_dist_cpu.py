@@ -108,3 +108,8 @@ def test_bench_py_multi_rank_plumbing_dry_run(gn_stats):
     assert out["config"]["global_batch"] == 6 and out["config"]["graphs_per_gpu"] == 3 and out["config"]["gn_stats"] == gn_stats
     assert out["config"]["nodes_rank0"] == 120 and out["config"]["edges_rank0"] == 720       # rank 0 holds 3 of the 6 graphs
     assert out["value"] > 0 and abs(out["value"] - 6 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    # evidence that the collective backend saw every rank: all-gathered world size, one loop time per rank
+    assert out["ranks_seen"] == 2 and len(out["rank_ms_per_step"]) == 2 and all(v > 0 for v in out["rank_ms_per_step"])
+    rep = out["repeats"]
+    assert rep["n"] == 3 and len(rep["ms_per_step"]) == 3
+    assert rep["min_ms_per_step"] <= rep["median_ms_per_step"] == out["ms_per_step"] <= rep["max_ms_per_step"]

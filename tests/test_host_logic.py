@@ -326,7 +326,7 @@ def test_mcts_heatmap_text_matches_reference(golden_dir, tmp_path):
         n, prob = int(z["num_nodes"]), float(z["expected_valid_prob"])
         text = formats.mcts_heatmap_text(z["heat"], z["points"], n, prob)
         assert text == bytes(z["text"]).decode()
-        out = formats.write_mcts_heatmap(z["heat"], z["points"], n, str(tmp_path), 0, expected_valid_prob=prob)
+        out = formats.write_mcts_heatmap(z["heat"], z["points"], n, str(tmp_path), 0, expected_valid_prob=prob, use_gpu=False)
         assert out.endswith(f"heatmap/tsp{n}/heatmaptsp{n}_0.txt") and open(out).read() == text
     hp, pp = formats.save_numpy_heatmap(z["heat"], z["points"], str(tmp_path), 3)
     assert hp.endswith("numpy_heatmap/test-heatmap-3.npy") and np.array_equal(np.load(hp), z["heat"])
@@ -515,8 +515,8 @@ def test_torch_ops_registered_and_host_ops_match_the_c_abi():
     assert ops.workspace_bytes(256, 12, 1000, 100000, 1) == _lib.lib().difusco_workspace_bytes(256, 12, 1000, 100000, 1)
     with pytest.raises(RuntimeError):          # CPU tensors are refused by the step ops (no CPU kernel is registered)
         z = torch.zeros(4)
-        ops.denoise_step_categorical(z, z.int(), z.int(), None, None, None, None, z, 1.0, [0.0] * 5, None, 0, 0, z, [64, 2, 2, 0, 3, 0, 1, 0],
-                                     False, False, None)
+        ops.denoise_step_categorical(z, z.int(), z.int(), None, None, None, None, z, 1.0, [0.0] * 5, None, 0, 0, z,
+                                     [64, 2, 2, 0, 3, 0, 1, 0, 0], False, False, None)      # (a valid 9-entry cfg: only the device is wrong)
 
 
 def test_mcts_text_from_sparse_heatmap_matches_reference(golden_dir, tmp_path):
@@ -528,7 +528,7 @@ def test_mcts_text_from_sparse_heatmap_matches_reference(golden_dir, tmp_path):
     ref_text = bytes(z["text"]).decode()
     assert ref_text.count("-0.000000") > 0          # the reference's signed zeros (both orientations negative) are covered
     path = formats.write_mcts_heatmap(z["heat"], z["points"], n, str(tmp_path), 0, expected_valid_prob=prob,
-                                      edge_index=z["edge_index"])
+                                      edge_index=z["edge_index"], use_gpu=False)
     assert path.endswith(f"heatmap/tsp{n}/heatmaptsp{n}_0.txt") and open(path).read() == ref_text
     rows_a = list(formats.mcts_heatmap_rows(z["heat"], z["edge_index"], z["points"], n, prob, block_rows=37))
     rows_b = list(formats.mcts_heatmap_rows(z["heat"], z["edge_index"], z["points"], n, prob, block_rows=1000))
@@ -537,10 +537,22 @@ def test_mcts_text_from_sparse_heatmap_matches_reference(golden_dir, tmp_path):
     import torch
     perm = np.random.default_rng(0).permutation(z["heat"].shape[0])
     path2 = formats.write_mcts_heatmap(torch.from_numpy(z["heat"][perm]), torch.from_numpy(z["points"]), n, str(tmp_path), 1,
-                                       expected_valid_prob=prob, edge_index=torch.from_numpy(z["edge_index"][:, perm].astype(np.int64)))
+                                       expected_valid_prob=prob, edge_index=torch.from_numpy(z["edge_index"][:, perm].astype(np.int64)),
+                                       use_gpu=False)
     assert open(path2).read() == ref_text
-    with pytest.raises(ValueError):
-        list(formats.mcts_heatmap_rows(np.ones(2, np.float32), np.array([[0, 0], [1, 1]]), z["points"][:4], 4, 0.5))
+    # the host program runs ONLY when asked for: the default (use_gpu=None) is the GPU kernels and raises on a GPU-less host
+    # instead of silently taking 31 s at N = 10^4
+    if not torch.cuda.is_available():
+        from difusco_amd import _lib
+        with pytest.raises(_lib.DifuscoHipError):
+            formats.write_mcts_heatmap(z["heat"], z["points"], n, str(tmp_path), 2, expected_valid_prob=prob,
+                                       edge_index=z["edge_index"])
+    # no positive entry at all: IndexError like the reference's valid_values[-k] on an empty array, also for k = 0
+    far = np.array([[0.0, 0.0], [3.0, 0.0], [0.0, 3.0], [3.0, 3.0]], np.float32)      # all distances > 1: the prior is negative
+    diag = np.array([[0, 1, 2, 3], [0, 1, 2, 3]])                                       # ... except on the diagonal (+0.01)
+    for pr in (0.5, 0.0):
+        with pytest.raises(IndexError):
+            list(formats.mcts_heatmap_rows(np.full(4, -5.0, np.float32), diag, far, 4, pr))
 
 
 def test_row_sum_program_is_numpys_own_order():
