@@ -311,7 +311,9 @@ int difusco_denoise_step(const difusco_step_args* a) {
 
   // fused edge-layer path: H = 256, 16-bit split planes, one GroupNorm statistic segment; e is then kept in the
   // tiled layout (kernels.h: edge_tiled_offset) from the embedding to the head
-  const bool fused = H == 256 && !a->no_fusion && E > 0 && a->n_segments == 1 &&
+  // (per-sample statistic segments - the dense mode of TSP-50 / 100 with parallel_sampling > 1 - run the same fused layers;
+  // only the head differs: masked per-segment statistics and a per-row segment look-up, launch_head_tiled)
+  const bool fused = H == 256 && !a->no_fusion && E > 0 &&
                      (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
   if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
   // the full-line neighbour-table gathers address node rows by 32-bit byte offsets (4 KB per node): calls with 2^20 nodes or
@@ -497,7 +499,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                       ws.partial, ws.stats, G(DIFUSCO_W_OUT_GN_W), G(DIFUSCO_W_OUT_GN_B),
                                       G(DIFUSCO_W_OUT_CONV_W), G(DIFUSCO_W_OUT_CONV_B), a->perm, a->xt, a->post,
                                       a->rand_mode, a->rand, a->seed, a->offset, a->xt_out, a->pred_out, a->prob_out, st,
-                                      gn_fold ? ws.gn_tile : nullptr, a->gn_phase, a->gn_sums))
+                                      gn_fold ? ws.gn_tile : nullptr, a->gn_phase, a->gn_sums,
+                                      a->n_segments > 1 ? a->seg_ptr : nullptr, a->n_segments))
     return finish();
   }
   PROF(PROF_HEAD, launch_head(H, C, tsp ? ws.e : ws.h, a->n_segments > 1 ? a->seg_ptr : nullptr, a->n_segments, out_rows,

@@ -350,8 +350,12 @@ struct PostParams {
   unsigned long long seed, offset;
 };
 
+// (No multiply-add contraction in the two posteriors: the reference evaluates them as separate fp32 torch operations, and
+// HIP's __fmul_rn / __fadd_rn are plain operators that hipcc's default -ffp-contract=fast may fuse - round 4 found the
+// Gaussian update off by one ulp of x_t on 0.6 % of the elements for that reason.)
 __device__ __forceinline__ float categorical_step(float l0, float l1, float xt, const PostParams& pp, long long idx,
                                                   float* prob_out) {
+#pragma clang fp contract(off)
   const float m = fmaxf(l0, l1);
   const float e0 = expf(l0 - m), e1 = expf(l1 - m);
   const float den = e0 + e1;
@@ -372,6 +376,7 @@ __device__ __forceinline__ float categorical_step(float l0, float l1, float xt, 
 // gaussian: pl_meta_model.py:161-172.  post = {a, b, c, d, branch}: branch 0 (DDIM)
 //   x = a*(xt - b*pred) + c*pred ; branch 1 (DDPM) x = a*(xt - b*pred) + d*z.
 __device__ __forceinline__ float gaussian_step(float pred, float xt, const PostParams& pp, long long idx) {
+#pragma clang fp contract(off)
   const float base = __fmul_rn(pp.p[0], __fsub_rn(xt, __fmul_rn(pp.p[1], pred)));
   if (pp.p[4] == 0.0f) return __fadd_rn(base, __fmul_rn(pp.p[2], pred));
   float z;
@@ -516,6 +521,52 @@ __global__ __launch_bounds__(256) void gn_partial_tiled_kernel(const float* __re
   }
 }
 
+// The same per STATISTIC SEGMENT (dense mode: one segment per sample, gnn_encoder.py:380; the segments need not be tile
+// aligned: rows outside [seg_ptr[s], seg_ptr[s+1]) of a straddling tile are masked).  grid (blocks, segments); wave w of a
+// block owns the groups 8 w .. 8 w + 7 of the tiles t0 + blockIdx.x, + gridDim.x, ...; every block writes all 32 groups
+// (partial[(seg * gridDim.x + block) * 64 + 2 g + {0, 1}]: the all-groups-per-block layout of gn_finalize_kernel).
+__global__ __launch_bounds__(256) void gn_partial_tiled_seg_kernel(const float* __restrict__ feat, const int* __restrict__ seg_ptr,
+                                                                   double* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
+  const int seg = blockIdx.y;
+  const long long r0 = seg_ptr[seg], r1 = seg_ptr[seg + 1];
+  double s[8], q[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = q[k] = 0.0;
+  if (r1 > r0) {
+    const long long t0 = r0 >> 5, t1 = (r1 - 1) >> 5;
+    for (long long t = t0 + blockIdx.x; t <= t1; t += gridDim.x) {
+      const long long row = t * 32 + l31;
+      if (row < r0 || row >= r1) continue;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const v4f x = *reinterpret_cast<const v4f*>(feat + t * 8192 + (8 * wave + k) * 256 + lane * 4);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          s[k] += (double)x[v];
+          q[k] += (double)x[v] * (double)x[v];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      s[k] += __shfl_xor(s[k], off, 64);
+      q[k] += __shfl_xor(q[k], off, 64);
+    }
+  }
+  if (lane == 0) {
+    double* dst = partial + ((long long)seg * gridDim.x + blockIdx.x) * 64 + 16 * wave;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      dst[2 * k] = s[k];
+      dst[2 * k + 1] = q[k];
+    }
+  }
+}
+
 // GroupNorm partial sums that the last fused edge layer left per tile (gn_tile[tile][32 groups][sum, sumsq] floats)
 // -> partial[256 blocks][64] doubles in the all-groups-per-block layout of gn_finalize_kernel (group stride 1).
 __global__ __launch_bounds__(256) void gn_tiles_reduce_kernel(const float* __restrict__ gn_tile, long long n_tiles,
@@ -531,14 +582,17 @@ __global__ __launch_bounds__(256) void gn_tiles_reduce_kernel(const float* __res
 
 // head on the tiled buffer: one wavefront per 32-edge tile; lane (l31, hh) accumulates the conv dot products of
 // edge l31 over its half of the channels, one cross-half exchange, then 32 lanes finish 32 edges at once.
-template <int C>
+// SEG: per-row statistic segments (seg_ptr [n_segments + 1], stats [n_segments][32][2]): every lane looks its edge's
+// segment up (binary search) and reads that segment's mean / rstd from memory instead of the block's LDS copy.
+template <int C, bool SEG>
 __global__ __launch_bounds__(256) void head_apply_tiled_kernel(const float* __restrict__ feat, long long rows,
                                                                long long n_tiles, const float* __restrict__ stats,
                                                                const float* __restrict__ gn_w, const float* __restrict__ gn_b,
                                                                const float* __restrict__ conv_w, const float* __restrict__ conv_b,
                                                                const int* __restrict__ perm, const float* __restrict__ xt,
                                                                PostParams pp, float* __restrict__ xt_out,
-                                                               float* __restrict__ pred_out, float* __restrict__ prob_out) {
+                                                               float* __restrict__ pred_out, float* __restrict__ prob_out,
+                                                               const int* __restrict__ seg_ptr, int n_segments) {
   // statistics and the per-channel parameters sit in LDS: every tile re-reads them, 4 channels per lane and chunk
   __shared__ float st[64];
   __shared__ __attribute__((aligned(16))) float s_gw[256], s_gb[256], s_cw[C][256];
@@ -553,6 +607,17 @@ __global__ __launch_bounds__(256) void head_apply_tiled_kernel(const float* __re
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
   for (long long t = wave0; t < n_tiles; t += nwaves) {
     const float* tp = feat + t * 8192 + lane * 4;
+    const float* st_row = stats;
+    if constexpr (SEG) {      // last segment whose first row is <= this lane's edge (pad lanes: the last segment)
+      long long srow = t * 32 + l31;
+      srow = srow < rows ? srow : rows - 1;
+      int lo = 0, hi = n_segments - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long long)seg_ptr[mid] <= srow) lo = mid; else hi = mid - 1;
+      }
+      st_row = stats + (long long)lo * 64;
+    }
     float dot[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) dot[c] = 0.0f;
@@ -560,7 +625,7 @@ __global__ __launch_bounds__(256) void head_apply_tiled_kernel(const float* __re
     for (int ch = 0; ch < 32; ++ch) {                 // chunk ch = 2 ks + i = GroupNorm group
       const v4f x = *reinterpret_cast<const v4f*>(tp + ch * 256);
       const int f = 8 * ch + 4 * hh;
-      const float mean = st[2 * ch], rstd = st[2 * ch + 1];
+      const float mean = SEG ? st_row[2 * ch] : st[2 * ch], rstd = SEG ? st_row[2 * ch + 1] : st[2 * ch + 1];
       const v4f gw = *reinterpret_cast<const v4f*>(s_gw + f), gb = *reinterpret_cast<const v4f*>(s_gb + f);
       v4f cw[C];
 #pragma unroll
@@ -793,9 +858,34 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
                              const float* gn_w, const float* gn_b, const float* conv_w, const float* conv_b,
                              const int* perm, const float* xt, const float* post, int rand_mode, const float* rand,
                              unsigned long long seed, unsigned long long offset, float* xt_out, float* pred_out,
-                             float* prob_out, hipStream_t stream, const float* gn_tile, int gn_phase, double* gn_sums) {
+                             float* prob_out, hipStream_t stream, const float* gn_tile, int gn_phase, double* gn_sums,
+                             const int* seg_ptr, int n_segments) {
   if (rows == 0) return hipSuccess;
   if (gn_phase != 0 && !gn_sums) return hipErrorInvalidValue;
+  if (n_segments > 1) {      // per-segment statistics (dense mode: one segment per sample): a masked pass over e per segment
+    if (!seg_ptr || gn_phase != 0) return hipErrorInvalidValue;
+    PostParams pq;
+    for (int i = 0; i < 8; ++i) pq.p[i] = post[i];
+    pq.rand_mode = rand_mode; pq.rand = rand; pq.seed = seed; pq.offset = offset;
+    const long long n_tiles_s = (rows + 31) / 32;
+    int bps = (int)((n_tiles_s / n_segments + 3) / 4);      // ~4 tiles per block
+    bps = bps < 1 ? 1 : (bps > 256 ? 256 : bps);
+    hipLaunchKernelGGL(gn_partial_tiled_seg_kernel, dim3(bps, n_segments), dim3(256), 0, stream, feat, seg_ptr, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_segments), dim3(1024), 0, stream, partial, seg_ptr, rows, bps, 8, 1, stats,
+                       (double*)nullptr);
+    long long blocks_s = (n_tiles_s + 3) / 4;
+    if (blocks_s > 4096) blocks_s = 4096;
+    if (C == 2) {
+      hipLaunchKernelGGL((head_apply_tiled_kernel<2, true>), dim3((unsigned)blocks_s), dim3(256), 0, stream, feat, rows, n_tiles_s,
+                         stats, gn_w, gn_b, conv_w, conv_b, perm, xt, pq, xt_out, pred_out, prob_out, seg_ptr, n_segments);
+    } else if (C == 1) {
+      hipLaunchKernelGGL((head_apply_tiled_kernel<1, true>), dim3((unsigned)blocks_s), dim3(256), 0, stream, feat, rows, n_tiles_s,
+                         stats, gn_w, gn_b, conv_w, conv_b, perm, xt, pq, xt_out, pred_out, prob_out, seg_ptr, n_segments);
+    } else {
+      return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   if (nblk < 8 || nblk % 8 != 0) return hipErrorInvalidValue;   // (with gn_tile, partial must hold 256 * 64 doubles)
   PostParams pp;
   for (int i = 0; i < 8; ++i) pp.p[i] = post[i];
@@ -817,11 +907,11 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
   long long blocks = (n_tiles + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   if (C == 2) {
-    hipLaunchKernelGGL((head_apply_tiled_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, feat, rows, n_tiles, stats,
-                       gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out, pred_out, prob_out);
+    hipLaunchKernelGGL((head_apply_tiled_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, stream, feat, rows, n_tiles, stats,
+                       gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out, pred_out, prob_out, (const int*)nullptr, 1);
   } else if (C == 1) {
-    hipLaunchKernelGGL((head_apply_tiled_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, stream, feat, rows, n_tiles, stats,
-                       gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out, pred_out, prob_out);
+    hipLaunchKernelGGL((head_apply_tiled_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, feat, rows, n_tiles, stats,
+                       gn_w, gn_b, conv_w, conv_b, perm, xt, pp, xt_out, pred_out, prob_out, (const int*)nullptr, 1);
   } else {
     return hipErrorInvalidValue;
   }

@@ -123,7 +123,7 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
                              const int* perm, const float* xt, const float* post, int rand_mode, const float* rand,
                              unsigned long long seed, unsigned long long offset, float* xt_out, float* pred_out,
                              float* prob_out, hipStream_t stream, const float* gn_tile = nullptr, int gn_phase = 0,
-                             double* gn_sums = nullptr);
+                             double* gn_sums = nullptr, const int* seg_ptr = nullptr, int n_segments = 1);
 hipError_t launch_edge_gate_aggregate(int H, int n_nodes, const int* rowptr, const int* col, const float* node4,
                                       float* ce_act, float* h, const float* nh_w, const float* nh_b, const float* ne_w,
                                       const float* ne_b, const float* ol_w, const float* ol_b, const float* tbias,

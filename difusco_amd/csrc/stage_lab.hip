@@ -295,22 +295,26 @@ __global__ __launch_bounds__(64 * WAVES, MINB) void stage_lab_kernel(const float
 #pragma unroll
     for (int u = 0; u < TPW; ++u)
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) asm volatile("" ::"v"(acc[u][nb]));
+      for (int nb = 0; nb < 8; ++nb) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the "v" constraint does not exist on the host pass: clang then drops the whole
+        asm volatile("" ::"v"(acc[u][nb]));      //  instantiation - stub included - without a diagnostic)
+#endif
+      }
   }
 }
 
 template <int EPW, int WAVES, int NBUF, int SYNC, int RING, int PRIO, int MINB, int DIST = NBUF - 1>
 hipError_t launch(const float* e, const unsigned short* planes, float* out, int n_edges, float inv_c, int do_store,
                   int lds_pad, hipStream_t st) {
-  auto kern = stage_lab_kernel<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST>;
   static std::atomic<unsigned long long> attr_devices{0};
-  hipError_t er = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(kern), 160 * 1024);
+  hipError_t er = ensure_max_dynamic_lds(
+      attr_devices, reinterpret_cast<const void*>(&stage_lab_kernel<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST>), 160 * 1024);
   if (er != hipSuccess) return er;
   const int per_wg = EPW * WAVES;
   if (n_edges % per_wg != 0) return hipErrorInvalidValue;
   const int lds = NBUF * BUF * 2 + 256 + lds_pad;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(n_edges / per_wg)), dim3(64 * WAVES), lds, st, e, planes, (long long)H * H, out,
-                     n_edges / 32, inv_c, do_store);
+  hipLaunchKernelGGL((stage_lab_kernel<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST>), dim3((unsigned)(n_edges / per_wg)),
+                     dim3(64 * WAVES), lds, st, e, planes, (long long)H * H, out, n_edges / 32, inv_c, do_store);
   return hipGetLastError();
 }
 

@@ -95,8 +95,7 @@ class DenoiseEngine:
         """The step-invariant part of a TSP step for (these weights, this graph, these coordinates) - node embedding,
         layer 0's node linear, the two-row edge-input table (``difusco_prepare``) - as an opaque device buffer to hand to
         ``step(prepared=...)``.  None when the fused path does not apply (the step then computes everything itself)."""
-        if not (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_segments == 1
-                and g.n_edges > 0):
+        if not (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_edges > 0):
             return None
         pts = points.to(self.device, dtype=torch.float32).contiguous()
         if pts.numel() != 2 * g.n_nodes:
@@ -111,7 +110,7 @@ class DenoiseEngine:
         a.abi_version = _lib.ABI_VERSION
         a.hidden, a.n_layers, a.out_channels, a.task = self.hidden, self.n_layers, self.out_channels, _lib.TASK_TSP
         a.weights = _ptr(self.blob)
-        a.n_nodes, a.n_edges, a.n_segments = g.n_nodes, g.n_edges, 1
+        a.n_nodes, a.n_edges, a.n_segments = g.n_nodes, g.n_edges, g.n_segments
         a.points = _ptr(pts)
         a.workspace, a.workspace_bytes = _ptr(ws), ws.numel()
         a.stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -357,3 +357,45 @@ def test_mcts_heatmap_default_is_the_gpu_path_for_any_input_dtype(dev, golden_di
     for pr in (0.5, 0.0):
         with pytest.raises(IndexError):
             list(formats.mcts_heatmap_rows_gpu(np.full(4, -5.0, np.float32), diag, far, 4, pr, device=dev))
+
+
+# ------------------------------------------------------------------------------------------------
+# per-sample GroupNorm segments on the fused path (dense mode with several samples)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("V,B", [(50, 4), (37, 3), (100, 2)])
+def test_dense_batch_through_the_fused_kernel_vs_oracle(dev, V, B):
+    """Dense TSP (``dense_forward``, ``gnn_encoder.py:350-381``: GroupNorm statistics PER SAMPLE) with B samples in one call - the
+    shape of TSP-50 / 100 with ``parallel_sampling > 1`` (``pl_tsp_model.py:178-192``).  Round 3 sent every call with more than one
+    statistic segment down the unfused kernel sequence; now the fused layers run and only the head is segment aware (V^2 is not
+    a multiple of 32: segments straddle tiles).  Default engine vs the oracle's dense encoder, vs the unfused sequence, and
+    sample b of the batch vs the same sample alone (per-sample statistics make them equal)."""
+    from difusco_amd import TSPModel
+    H, Lyr = 256, 12
+    p = O.init_params(H, Lyr, 2, seed=20240926)
+    g = torch.Generator().manual_seed(V * 10 + B)
+    pts = torch.rand(B, V, 2, generator=g)
+    xt = (torch.randn(B, V, V, generator=g) > 0).float()
+    u = torch.rand(B, V, V, generator=g)
+    t, tt = 500, 469
+    ref_out, ref_logits, ref_prob = O.tsp_categorical_denoise_step(p, O.CategoricalTables(), pts, xt, t, None, tt, uniform=u,
+                                                                   return_aux=True)
+    ref_logits = ref_logits.permute(0, 2, 3, 1) if ref_logits.shape[1] == 2 and ref_logits.dim() == 4 else ref_logits
+    m = TSPModel(_args("categorical", -1), p, device=dev)
+    out, lg, pr = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, None, target_t=np.array([tt]),
+                                             uniform=u.reshape(-1), return_aux=True)
+    e_log = (lg.cpu().reshape(ref_logits.shape) - ref_logits).abs().max().item()
+    e_prob = (pr.cpu().reshape(-1) - ref_prob.reshape(-1)).abs().max().item()
+    print(f"dense V={V} B={B} H=256 L=12 (fused layers, per-sample statistics) vs oracle: logits L_inf {e_log:.3e}, prob {e_prob:.3e}")
+    assert e_log < TOL and e_prob < TOL
+    safe = (u.reshape(-1) - ref_prob.reshape(-1)).abs() > 1e-4
+    assert torch.equal(out.cpu().reshape(-1)[safe], ref_out.reshape(-1)[safe])
+    mu = TSPModel(_args("categorical", -1), p, device=dev, fused=False)
+    _, lu, pu = mu.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, None, target_t=np.array([tt]),
+                                            uniform=u.reshape(-1), return_aux=True)
+    assert (lg - lu).abs().max().item() < 5e-5 and (pr - pu).abs().max().item() < 5e-5
+    for b in (0, B - 1):          # a sample alone (one segment: the round-3 fused path) == the same sample inside the batch
+        _, l1, _ = m.categorical_denoise_step(pts[b:b + 1].to(dev), xt[b:b + 1].to(dev), np.array([t]), dev, None,
+                                              target_t=np.array([tt]), uniform=u[b].reshape(-1), return_aux=True)
+        e_b = (lg.reshape(B, V, V, 2)[b] - l1.reshape(V, V, 2)).abs().max().item()
+        print(f"  sample {b} in the batch vs alone: logits L_inf {e_b:.3e}")
+        assert e_b < 2e-5

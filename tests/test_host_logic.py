@@ -33,6 +33,18 @@ def test_library_exports_every_declared_symbol():
         assert not hasattr(L, n), f"{n} must not be exported by the production library"
 
 
+def test_profiling_library_loads():
+    """libdifusco_hip_prof.so (timing-only kernel variants, stage-loop laboratory) must at least LOAD: an unresolved kernel stub
+    only shows at dlopen time (round 4: an inline-asm "v" constraint made clang drop a whole kernel-template instantiation on
+    the host pass without a diagnostic)."""
+    from difusco_amd.build import PROF_LIB_PATH
+    if not os.path.exists(PROF_LIB_PATH):
+        pytest.skip("profiling library not built (python -m difusco_amd.build --prof)")
+    P = ctypes.CDLL(PROF_LIB_PATH)
+    for n in ("difusco_debug_set", "difusco_debug_set_ptr", "difusco_lab_gemm1", "difusco_denoise_step"):
+        assert hasattr(P, n)
+
+
 def test_step_args_abi_is_checked():
     a = _lib.StepArgs()
     a.struct_size = 8          # wrong on purpose
