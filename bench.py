@@ -221,8 +221,8 @@ def main():
                     "tsp500, tsp10000, mis - a few timed steps each with their own roofline, cpu_baseline and parity_linf)")
     ap.add_argument("--repeats", type=int, default=3, help="repetitions of the timed K-step loop (each between its own fences); the "
                     "headline is the median repetition, all of them are listed under `repeats`")
-    ap.add_argument("--backend", default="ctypes", choices=["ctypes", "torch"], help="host binding of the C ABI: ctypes, or the "
-                    "PyTorch custom ops torch.ops.difusco.* (csrc/torch_ops.cpp)")
+    ap.add_argument("--backend", default=None, choices=["ctypes", "torch"], help="host binding of the C ABI: the PyTorch custom ops "
+                    "torch.ops.difusco.* (csrc/torch_ops.cpp; the default) or ctypes (the default with the profiling library)")
     ap.add_argument("--no-prepare", action="store_true", help="A/B: recompute the step-invariant part of a TSP step (node "
                     "embedding, layer-0 node linear, time-bias rows) in every step instead of once per (graph, schedule)")
     ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of each `workloads` entry (2 warm-up steps)")
@@ -324,12 +324,9 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         dist.barrier()
         tb0 = time.perf_counter()
         engine = engine_from_broadcast(params, device, src=0, precision=args.precision, fused=not args.no_fusion,
-                                       flags=step_flags)
+                                       flags=step_flags, backend=args.backend)
         torch.cuda.synchronize(device)
         broadcast_ms = 1e3 * (time.perf_counter() - tb0)      # rank-0 packing + the RCCL broadcast of the blob
-        if args.backend != "ctypes":
-            engine = DenoiseEngine(device=device, blob=engine.blob, config=(engine.hidden, engine.n_layers, engine.out_channels),
-                                   precision=args.precision, fused=not args.no_fusion, flags=step_flags, backend=args.backend)
     else:
         engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion, flags=step_flags,
                                backend=args.backend)
@@ -512,7 +509,8 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
                        "fused_edge_layer": (not args.no_fusion) and args.precision in ("bf16x3", "fp16x3"),
                        "node_order": "caller" if (args.no_node_reorder or mis) else "morton per graph (graph.py)",
                        "fused_opt": args.fused_opt, "debug_set": args.debug_set or None, "streams": args.streams,
-                       "binding": ("ctypes -> C ABI" if args.backend == "ctypes" else "torch.ops.difusco.* custom ops -> C ABI"),
+                       "binding": ("dry run" if engine is None else "ctypes -> C ABI" if engine.backend == "ctypes" else
+                                   "torch.ops.difusco.* custom ops -> C ABI"),
                        "prepared_state": (not args.no_prepare)},
         }
         if prof is not None and prof["launches"][0] > 0:

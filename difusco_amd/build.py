@@ -85,9 +85,27 @@ def rocm_root() -> str:
     return root if os.path.isdir(os.path.join(root, "include")) else "/opt/rocm"
 
 
-def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str:
-    """Compile every HIP source for gfx950 into one shared library; returns its path.  prof: the profiling library."""
+# A/B builds of the production sources with different compiler options (benchmarking only; loaded through
+# DIFUSCO_HIP_LIBRARY=<path>): name -> (extra flags, the sources they apply to; None = every source)
+NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]      # no v_pk_{add,mul,fma}_f32: plain fp32 VALU
+VARIANTS = {
+    "nopk_fused": (NO_PK, ("edge_layer.hip", "edge_layer_bf16.hip")),
+    "nopk_all": (NO_PK, None),
+}
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(LIB_DIR, f"libdifusco_hip_{name}.so")
+
+
+def build(force: bool = False, verbose: bool = False, prof: bool = False, variant: str = None) -> str:
+    """Compile every HIP source for gfx950 into one shared library; returns its path.  prof: the profiling library;
+    variant: one of VARIANTS (an A/B build of the production sources, libdifusco_hip_<variant>.so)."""
     lib_path, sources = (PROF_LIB_PATH, PROF_SOURCES) if prof else (LIB_PATH, SOURCES)
+    var_flags, var_sources = [], ()
+    if variant is not None:
+        lib_path = variant_path(variant)
+        var_flags, var_sources = VARIANTS[variant]
     if not force and not _stale(lib_path, sources):
         return lib_path
     hipcc = _hipcc()
@@ -98,15 +116,20 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> str
     with tempfile.TemporaryDirectory(prefix="difusco_build_") as tmp:
         def compile_one(src):
             obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
-            cmd = [hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+            extra = EXTRA_FLAGS.get(src, []) + (var_flags if (var_sources is None or src in var_sources) else [])
+            if src == "stage_lab.hip@nopk":      # the stage-loop laboratory a second time, without packed fp32 arithmetic
+                src, extra = "stage_lab.hip", extra + NO_PK + ["-DDIFUSCO_LAB_NOPK=1"]
+                obj = os.path.join(tmp, "stage_lab_nopk.o")
+            cmd = [hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
                 raise RuntimeError(f"hipcc failed on {src}:\n" + res.stdout + res.stderr)
             return obj
-        with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 4)) as pool:
-            objs = list(pool.map(compile_one, sources))
+        todo = list(sources) + (["stage_lab.hip@nopk"] if prof else [])
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as pool:
+            objs = list(pool.map(compile_one, todo))
         cmd = [hipcc] + flags + ["-shared", "-o", lib_path] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -121,3 +144,6 @@ if __name__ == "__main__":
     print(build_torch_ops(force="--force" in sys.argv, verbose=True))
     if "--prof" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, prof=True))
+    for name in VARIANTS:
+        if "--variant=" + name in sys.argv:
+            print(build(force="--force" in sys.argv, verbose=True, variant=name))

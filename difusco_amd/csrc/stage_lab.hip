@@ -24,8 +24,18 @@
 #ifdef DIFUSCO_PROFILING
 #include "../../include/difusco_hip.h"
 
+// The file is compiled twice into the profiling library: as is, and with -DDIFUSCO_LAB_NOPK under the target feature
+// -packed-fp32-ops (the operand split then uses plain v_sub_f32 instead of v_pk_add_f32): difusco_lab_gemm1_nopk.
+#ifdef DIFUSCO_LAB_NOPK
+#define LAB_NS lab_nopk
+#define LAB_ENTRY difusco_lab_gemm1_nopk
+#else
+#define LAB_NS lab
+#define LAB_ENTRY difusco_lab_gemm1
+#endif
+
 namespace difusco {
-namespace lab {
+namespace LAB_NS {
 
 constexpr int H = 256;
 constexpr int NS = 16;                 // stages = k slabs of C
@@ -318,7 +328,7 @@ hipError_t launch(const float* e, const unsigned short* planes, float* out, int 
   return hipGetLastError();
 }
 
-}  // namespace lab
+}  // namespace LAB_NS
 }  // namespace difusco
 
 extern "C" {
@@ -326,9 +336,9 @@ extern "C" {
 // (64-edge waves and 8-wave workgroups are one workgroup per CU, the production geometry two).  planes: the fp16 hi | lo
 // planes of C (weights.split_planes output + 3 H H 16-bit elements); e / out tiled [n_edges, 256]; n_edges a multiple of the
 // edges per workgroup.  lds_pad: extra dynamic LDS bytes (to pin the number of co-resident workgroups).
-int difusco_lab_gemm1(int variant, const float* e, const void* planes, float* out, int n_edges, float inv_c, int do_store,
-                      int lds_pad, void* stream) {
-  using namespace difusco::lab;
+int LAB_ENTRY(int variant, const float* e, const void* planes, float* out, int n_edges, float inv_c, int do_store,
+              int lds_pad, void* stream) {
+  using namespace difusco::LAB_NS;
   const unsigned short* pl = reinterpret_cast<const unsigned short*>(planes);
   hipStream_t st = (hipStream_t)stream;
   hipError_t er = hipErrorInvalidValue;

@@ -6,6 +6,8 @@
 //   prepare_graph(edge_index, n_nodes) -> (rowptr, col, row, perm, identity)         host, CPU tensors
 //   weights_layout(hidden, n_layers, out_channels) -> int64[entries + 1]              offsets, last = total floats
 //   workspace_bytes(hidden, n_layers, n_nodes, n_edges, n_segments) -> int
+//   prepare_state(weights, points, n_nodes, n_edges, n_segments, workspace, cfg) -> uint8 buffer     difusco_prepare
+//   time_bias_rows(weights, times, cfg) -> float32 [n_t, n_layers, hidden]                            difusco_time_bias_rows
 //   denoise_step_categorical(...) / denoise_step_gaussian(...) -> (xt_next, pred, prob)
 //       replace {categorical,gaussian}_denoise_step of difusco/pl_tsp_model.py:122-151 / pl_mis_model.py:118-140
 //
@@ -145,6 +147,52 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
   return {xt_out, pred, prob};
 }
 
+// Prepared state (include/difusco_hip.h, ABI 9): the step-invariant part of a TSP step for (weights, graph, points), and the
+// time-bias rows of a whole schedule.  cfg as in step_impl (only hidden, n_layers, out_channels, precision are read).
+at::Tensor prepare_state(const at::Tensor& weights, const at::Tensor& points, int64_t n_nodes, int64_t n_edges,
+                         int64_t n_segments, at::Tensor workspace, c10::ArrayRef<int64_t> cfg) {
+  TORCH_CHECK(cfg.size() == 9, "cfg = {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}");
+  need(weights, at::kFloat, "weights", true);
+  need(points, at::kFloat, "points", true);
+  TORCH_CHECK(points.numel() == 2 * n_nodes, "points must be [n_nodes, 2]");
+  TORCH_CHECK(workspace.is_cuda() && workspace.is_contiguous(), "workspace must be a contiguous GPU tensor");
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(weights.device());
+  const size_t bytes = difusco_prepared_bytes((int)cfg[0], (int)n_nodes);
+  TORCH_CHECK(bytes > 0, "difusco_prepared_bytes rejected the shape");
+  at::Tensor out = at::empty({(int64_t)bytes}, weights.options().dtype(at::kByte));
+  difusco_step_args a{};
+  a.struct_size = sizeof(difusco_step_args);
+  a.abi_version = DIFUSCO_ABI_VERSION;
+  a.hidden = (int)cfg[0];
+  a.n_layers = (int)cfg[1];
+  a.out_channels = (int)cfg[2];
+  a.task = DIFUSCO_TASK_TSP;
+  a.weights = weights.data_ptr<float>();
+  a.n_nodes = (int32_t)n_nodes;
+  a.n_edges = (int32_t)n_edges;
+  a.n_segments = (int32_t)n_segments;
+  a.points = points.data_ptr<float>();
+  a.workspace = workspace.data_ptr();
+  a.workspace_bytes = (size_t)workspace.nbytes();
+  a.stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(weights.device().index()).stream();
+  a.precision = (int32_t)cfg[4];
+  check(difusco_prepare(&a, out.data_ptr(), bytes), "difusco_prepare");
+  return out;
+}
+
+at::Tensor time_bias_rows(const at::Tensor& weights, c10::ArrayRef<double> times, c10::ArrayRef<int64_t> cfg) {
+  TORCH_CHECK(cfg.size() == 9 && !times.empty(), "cfg (9 entries) and at least one time required");
+  need(weights, at::kFloat, "weights", true);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(weights.device());
+  std::vector<float> t(times.begin(), times.end());
+  at::Tensor out = at::empty({(int64_t)t.size(), cfg[1], cfg[0]}, weights.options());
+  check(difusco_time_bias_rows((int)cfg[0], (int)cfg[1], (int)cfg[2], weights.data_ptr<float>(), t.data(), (int)t.size(),
+                               out.data_ptr<float>(),
+                               (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(weights.device().index()).stream()),
+        "difusco_time_bias_rows");
+  return out;
+}
+
 #define STEP_SIGNATURE                                                                                                   \
   const at::Tensor &weights, const at::Tensor &rowptr, const at::Tensor &col, const c10::optional<at::Tensor>&perm,     \
       const c10::optional<at::Tensor>&row, const c10::optional<at::Tensor>&seg_ptr,                                     \
@@ -175,6 +223,8 @@ TORCH_LIBRARY(difusco, m) {
   m.def("weights_layout(int hidden, int n_layers, int out_channels) -> Tensor", &weights_layout);
   m.def("workspace_bytes(int hidden, int n_layers, int n_nodes, int n_edges, int n_segments) -> int", &workspace_bytes);
   m.def("abi_version() -> int", []() -> int64_t { return difusco_abi_version(); });
+  m.def("prepare_state(Tensor weights, Tensor points, int n_nodes, int n_edges, int n_segments, Tensor(a!) workspace, int[] cfg) -> Tensor");
+  m.def("time_bias_rows(Tensor weights, float[] times, int[] cfg) -> Tensor");
   m.def((std::string("denoise_step_categorical") + kStepSchema).c_str());
   m.def((std::string("denoise_step_gaussian") + kStepSchema).c_str());
 }
@@ -183,6 +233,8 @@ TORCH_LIBRARY_IMPL(difusco, CPU, m) { m.impl("prepare_graph", &prepare_graph); }
 
 // ROCm builds of PyTorch dispatch HIP tensors under the CUDA key
 TORCH_LIBRARY_IMPL(difusco, CUDA, m) {
+  m.impl("prepare_state", &prepare_state);
+  m.impl("time_bias_rows", &time_bias_rows);
   m.impl("denoise_step_categorical", &denoise_step_categorical);
   m.impl("denoise_step_gaussian", &denoise_step_gaussian);
 }

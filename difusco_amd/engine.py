@@ -18,7 +18,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class DenoiseEngine:
     def __init__(self, state_dict=None, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
-                 fused: bool = True, backend: str = "ctypes", flags: int = 0, config=None):
+                 fused: bool = True, backend: Optional[str] = None, flags: int = 0, config=None):
         """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
         ``blob`` + ``config=(hidden, n_layers, out_channels)``: an already packed blob (e.g. received by RCCL broadcast)
         instead of a state_dict to pack here."""
@@ -45,6 +45,13 @@ class DenoiseEngine:
         self.precision = precision
         self.fused = fused          # fused edge-layer kernel (H == 256, precision bf16x3 / fp16x3)
         self.flags = int(flags)     # difusco_step_args.flags (_lib.FLAG_*): per-call A/B switches of the fused path
+        if backend is None:
+            # default binding = the PyTorch custom ops (what BASELINE.json's north_star names; same speed as ctypes, bench.py
+            # A/B); the ctypes binding when the ops cannot apply: profiling library / DIFUSCO_HIP_LIBRARY behind ctypes (the
+            # ops are linked against the production library), or libdifusco_torch.so not built
+            from .build import LIB_PATH, TORCH_LIB_PATH
+            same = os.path.realpath(_lib.loaded_path()) == os.path.realpath(LIB_PATH)
+            backend = "torch" if (same and os.path.exists(TORCH_LIB_PATH)) else "ctypes"
         if backend not in ("ctypes", "torch"):
             raise ValueError("backend must be 'ctypes' (C ABI through ctypes) or 'torch' (torch.ops.difusco custom ops)")
         self.backend = backend
@@ -73,6 +80,11 @@ class DenoiseEngine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def _cfg(self, task: int = _lib.TASK_TSP, xt_is_binary: bool = False, phase: int = 0):
+        """cfg list of the torch ops: {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}"""
+        return [self.hidden, self.n_layers, self.out_channels, task, _lib.PRECISIONS[self.precision], 0 if self.fused else 1,
+                1 if xt_is_binary else 0, phase, self.flags]
+
     # ---- prepared state (difusco_step_args.prepared / .tbias) --------------------------------------
     def prepare_times(self, ts) -> None:
         """Time-bias rows of every diffusion time in ``ts`` (e.g. the 50 steps of a schedule) in ONE launch; ``step`` then
@@ -80,12 +92,15 @@ class DenoiseEngine:
         todo = sorted({float(t) for t in ts} - set(self._tbias))
         if not todo:
             return
-        out = torch.empty((len(todo), self.n_layers, self.hidden), dtype=torch.float32, device=self.device)
-        arr = (ctypes.c_float * len(todo))(*todo)
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().difusco_time_bias_rows(
-                self.hidden, self.n_layers, self.out_channels, _ptr(self.blob), arr, len(todo), _ptr(out),
-                ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        if self.backend == "torch":
+            out = self._ops.time_bias_rows(self.blob, todo, self._cfg())
+        else:
+            out = torch.empty((len(todo), self.n_layers, self.hidden), dtype=torch.float32, device=self.device)
+            arr = (ctypes.c_float * len(todo))(*todo)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().difusco_time_bias_rows(
+                    self.hidden, self.n_layers, self.out_channels, _ptr(self.blob), arr, len(todo), _ptr(out),
+                    ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         if len(self._tbias) > 4096:
             self._tbias.clear()
         for i, t in enumerate(todo):
@@ -102,9 +117,11 @@ class DenoiseEngine:
             raise ValueError("points must be [n_nodes, 2]")
         if g.node_order is not None:
             pts = pts.reshape(-1, 2).index_select(0, g.node_order)
+        ws = self._workspace(g)
+        if self.backend == "torch":
+            return self._ops.prepare_state(self.blob, pts, g.n_nodes, g.n_edges, g.n_segments, ws, self._cfg())
         need = _lib.lib().difusco_prepared_bytes(self.hidden, g.n_nodes)
         buf = torch.empty(need, dtype=torch.uint8, device=self.device)
-        ws = self._workspace(g)
         a = _lib.StepArgs()
         a.struct_size = ctypes.sizeof(_lib.StepArgs)
         a.abi_version = _lib.ABI_VERSION
@@ -212,8 +229,7 @@ class DenoiseEngine:
                        want_prob, gn_reduce, ws, prepared=None, tbias=None):
         """The same step through ``torch.ops.difusco.denoise_step_{categorical,gaussian}`` (csrc/torch_ops.cpp)."""
         op = self._ops.denoise_step_categorical if diffusion == _lib.CATEGORICAL else self._ops.denoise_step_gaussian
-        cfg = [self.hidden, self.n_layers, self.out_channels, task, _lib.PRECISIONS[self.precision], 0 if self.fused else 1,
-               1 if xt_is_binary else 0, 0, self.flags]
+        cfg = self._cfg(task, xt_is_binary)
         seg = g.seg_ptr if g.n_segments > 1 else None
         post = [float(v) for v in post]
 

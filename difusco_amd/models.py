@@ -44,7 +44,7 @@ class COMetaModel:
 
     def __init__(self, param_args=None, state_dict=None, node_feature_only=False, device="cuda:0",
                  seed: Optional[int] = None, engine: Optional[DenoiseEngine] = None, precision: str = "fp16x3",
-                 fused: bool = True, gn_reduce=None, reorder_nodes: bool = True, backend: str = "ctypes", flags: int = 0,
+                 fused: bool = True, gn_reduce=None, reorder_nodes: bool = True, backend: Optional[str] = None, flags: int = 0,
                  prepare: bool = True, strict_binary_check: bool = False):
         args = dict(_DEFAULTS)
         if param_args is not None:

@@ -372,6 +372,9 @@ int difusco_debug_set_ptr(int key, void* p);
  * planes; do_store 0 = timing only; lds_pad = extra dynamic LDS bytes.  scripts/bench_stage_lab.py drives it. */
 int difusco_lab_gemm1(int variant, const float* e, const void* planes, float* out, int n_edges, float inv_c, int do_store,
                       int lds_pad, void* stream);
+/* the same translation unit compiled without packed fp32 arithmetic (target feature -packed-fp32-ops) */
+int difusco_lab_gemm1_nopk(int variant, const float* e, const void* planes, float* out, int n_edges, float inv_c, int do_store,
+                           int lds_pad, void* stream);
 #endif
 
 #ifdef __cplusplus

@@ -21,13 +21,15 @@ from difusco_amd import _lib, graph, weights  # noqa: E402
 ALL = [142020, 142120, 143120, 143130, 143121, 143220, 144220,
        242020, 243120, 244120, 244130, 244121, 244220,
        182020, 183120, 184120, 184121, 184220]
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 and sys.argv[1] else ALL
+# a trailing "n" selects the translation unit compiled WITHOUT packed fp32 arithmetic (difusco_lab_gemm1_nopk)
+variants = [v for v in sys.argv[1].split(",")] if len(sys.argv) > 1 and sys.argv[1] else [str(v) for v in ALL]
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 800_000
 H = 256
 dev = torch.device("cuda:0")
 L = _lib.lib()
-L.difusco_lab_gemm1.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
-                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+for fn in (L.difusco_lab_gemm1, L.difusco_lab_gemm1_nopk):
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                   ctypes.c_int, ctypes.c_void_p]
 gen = torch.Generator().manual_seed(0)
 x = torch.randn(E, H, generator=gen)
 Wc = (torch.rand(H, H, generator=gen) * 2 - 1) / 16
@@ -41,7 +43,8 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 
 
 def run(v, store):
-    _lib.check(L.difusco_lab_gemm1(v, P(e_t), P(fp16_planes), P(out), E, inv_c, store, 0, st))
+    fn = L.difusco_lab_gemm1_nopk if v.endswith("n") else L.difusco_lab_gemm1
+    _lib.check(fn(int(v.rstrip("n")), P(e_t), P(fp16_planes), P(out), E, inv_c, store, 0, st))
 
 
 # correctness: the first / last 4096 edges against float64
