@@ -17,7 +17,8 @@ for wl in tsp500 mis tsp10000; do
   timeout 300 python bench.py $AB --workload $wl --steps 10 > $OUT/wl_${wl}_prod.json 2> $OUT/wl_${wl}_prod.err
   DIFUSCO_HIP_LIBRARY=$REPO/difusco_amd/lib/libdifusco_hip_nopk_all.so timeout 300 python bench.py $AB --workload $wl --steps 10 > $OUT/wl_${wl}_nopkall.json 2> $OUT/wl_${wl}_nopkall.err
 done
-DIFUSCO_HIP_LIBRARY=$REPO/difusco_amd/lib/libdifusco_hip_nopk_all.so timeout 900 python -m pytest tests/test_gpu_round4.py tests/test_gpu_parity.py -q -s --maxfail=20 -k "round4 or oracle or golden or bench_workload or posterior" > $OUT/pytest_nopk.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_nopk.log
+DIFUSCO_HIP_LIBRARY=$REPO/difusco_amd/lib/libdifusco_hip_nopk_all.so timeout 900 python -m pytest tests/test_gpu_parity.py -q -s --maxfail=20 -k "oracle or golden or bench_workload or posterior or fused" > $OUT/pytest_nopk.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_nopk.log
+DIFUSCO_HIP_LIBRARY=$REPO/difusco_amd/lib/libdifusco_hip_nopk_all.so timeout 900 python -m pytest tests/test_gpu_round4.py -q -s --maxfail=20 > $OUT/pytest_nopk_r4.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_nopk_r4.log
 timeout 900 python -m pytest tests/test_gpu_round4.py -q -s --maxfail=20 > $OUT/pytest_round4.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_round4.log
 LDS_PAD=4000 STAMP_VARIANT=18 timeout 300 python scripts/bench_fused_layer.py fp16x3 "0/20339" > $OUT/stamps_1wg.txt 2>&1
 python - <<'PY'
@@ -32,5 +33,5 @@ for f in sorted(glob.glob("gpurun_out/r04c/*.json")):
         print(f, "unreadable", e)
 PY
 tail -12 $OUT/stage_lab_pk.txt | cut -c1-200
-grep -E "passed|failed|FAILED|Error" $OUT/pytest_nopk.log | tail; grep -E "passed|failed|FAILED|Error" $OUT/pytest_round4.log | tail
+grep -E "passed|failed|FAILED|Error" $OUT/pytest_nopk.log | tail; grep -E "passed|failed|FAILED|Error" $OUT/pytest_nopk_r4.log | tail; grep -E "passed|failed|FAILED|Error" $OUT/pytest_round4.log | tail
 grep -E "median|phase stamps|ticks" $OUT/stamps_1wg.txt | head -14
