@@ -29,9 +29,18 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.p
 # one they need 234-242 and no scratch, and the step is 3.7 % faster (DIFUSCO_FUSED_SCHED=default restores the default).
 _FUSED_SCHED = os.environ.get("DIFUSCO_FUSED_SCHED", "iterative-maxocc")
 EXTRA_FLAGS = {}
-if _FUSED_SCHED != "default":
-    for _src in ("edge_layer.hip", "edge_layer_bf16.hip", "edge_layer_abl.hip"):
-        EXTRA_FLAGS[_src] = ["-mllvm", "-amdgpu-sched-strategy=" + _FUSED_SCHED]
+# No packed fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma_f32) in the fused edge-layer kernels.  On gfx950 a packed fp32
+# operation has the throughput of two plain ones (the vector peak, 256 flop/clk/CU, is already reached by v_fma_f32) and is an
+# anti-lever beside MFMAs (MI355X_MICROARCH.md, "price of one filler": one v_pk_fma_f32 costs +22 cycles against two v_fma_f32);
+# the kernel issues ~1,600 of them per tile next to the partner wave's matrix phases.  Same-box A/B (profiles/r04/
+# exp_packed_fp32.txt): TSP-1000 +2.3 %, MIS +2.2 %, TSP-10000 +2.0 %, TSP-500 +1.6 %.  The source keeps its v2f pair
+# arithmetic: with the target feature off the backend splits every pair operation into two plain ones on the adjacent
+# registers - no moves (DIFUSCO_FUSED_PACKED_FP32=1 restores the packed instructions for an A/B).
+NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+_FUSED_NO_PK = os.environ.get("DIFUSCO_FUSED_PACKED_FP32", "0") in ("", "0")
+for _src in ("edge_layer.hip", "edge_layer_bf16.hip", "edge_layer_abl.hip"):
+    EXTRA_FLAGS[_src] = (["-mllvm", "-amdgpu-sched-strategy=" + _FUSED_SCHED] if _FUSED_SCHED != "default" else []) + \
+                        (NO_PK if _FUSED_NO_PK else [])
 
 # formats.hip reproduces a numpy float32 program bit for bit: IEEE divide / square root, no multiply-add contraction
 EXTRA_FLAGS["formats.hip"] = ["-fhip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=off"]
@@ -87,9 +96,8 @@ def rocm_root() -> str:
 
 # A/B builds of the production sources with different compiler options (benchmarking only; loaded through
 # DIFUSCO_HIP_LIBRARY=<path>): name -> (extra flags, the sources they apply to; None = every source)
-NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]      # no v_pk_{add,mul,fma}_f32: plain fp32 VALU
 VARIANTS = {
-    "nopk_fused": (NO_PK, ("edge_layer.hip", "edge_layer_bf16.hip")),
+    "pk_fused": (["-Xclang", "-target-feature", "-Xclang", "+packed-fp32-ops"], ("edge_layer.hip", "edge_layer_bf16.hip")),   # round 3
     "nopk_all": (NO_PK, None),
 }
 

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //   bit 12 persistent workgroups, bit 13 gathers two batches ahead (both measured slower, profiling library only);
   //   bit 14 FULL-LINE neighbour-table gathers through LDS-DMA (+3.4 %, see the gather phase), bit 15 two units + counted waits (no
   //          further gain, profiling library only).
-  // Production = 20339 (bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14).  Bits 0-11 = 3955: +16 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
+  //   bit 17 neighbour-sum fast path for tiles with one centre node (round 4, bit-identical).
+  // Production = 151411 (bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14, 17).  Bits 0-11 = 3955: +16 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
   // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5, 8-10 do not change a result bit; bit 6
   // changes the summation order of the LayerNorm statistics and bit 11 where the compiler contracts multiply-adds (fp32
@@ -518,6 +519,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // v_pk_fma_f32 without the v_mov pairs hipcc's own vectoriser needed for the pairs it chose; element for element the same
   // operations in the same order as the scalar code (requires bit 6: the partial sums are the pairs' running sums)
   constexpr bool kPk = (OPT & 2048) != 0;
+  // OPT bit 17: fast path of the neighbour sum for tiles that hold ONE centre node (see FUSED_AGG_ROUND); bit-identical
+  constexpr bool kAggFast = (OPT & 131072) != 0;
   static_assert(!kPk || kPart, "OPT bit 11 needs bit 6");
   float s1 = 0.0f, s1p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   v2f s1k[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
@@ -557,6 +560,20 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
         /* two halves of 16 rows: 32 values in flight at once is the register peak of the kernel (128 accumulators + the */  \
         /* gather buffers are live here) and made the compiler spill accumulators */                                         \
         float accv = 0.0f;                                                                                                   \
+        if (kAggFast && bnd == 0) {                                                                                          \
+          /* (wave uniform) ONE centre node in the whole tile - 68 % of the tiles at K = 100: plain column sums in the */    \
+          /* same order, without the per-row boundary tests (5 scalar instructions + a taken branch per row) */              \
+_Pragma("unroll")                                                                                                         \
+          for (int half = 0; half < 2; ++half) {                                                                             \
+            float v[16];                                                                                                     \
+_Pragma("unroll")                                                                                                         \
+            for (int k = 0; k < 16; ++k) v[k] = scr[(16 * half + k) * SCR_STRIDE + lane];                                    \
+_Pragma("unroll")                                                                                                         \
+            for (int kk = 0; kk < 16; ++kk) accv += v[kk];                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+          }                                                                                                                  \
+          part0[f] = accv;                                                                                                   \
+        } else {                                                                                                             \
 _Pragma("unroll")                                                                                                         \
         for (int half = 0; half < 2; ++half) {                                                                               \
           float v[16];                                                                                                       \
@@ -577,6 +594,7 @@ _Pragma("unroll")                                                               
         }                                                                                                                    \
         float* dst = (first_end == 32) ? part0 : part1;                                                                      \
         dst[f] = accv;                                                                                                       \
+        }                                                                                                                    \
       }                                                                                                                      \
       __builtin_amdgcn_wave_barrier();
   // OPT bit 14 (experiment): A h[j] / V h[j] by FULL-LINE gathers.  With lane = edge every gather instruction touches 32 rows x
@@ -1221,7 +1239,7 @@ _Pragma("unroll")                                                               
 #define FUSED_DBG nullptr
 #define FUSED_START_DELAY 0
 #endif
-#define FUSED_OPT 20339      // production options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14 of the kernel)
+#define FUSED_OPT 151411     // production options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14, 17 of the kernel)
 #define FUSED_OPT_R2 3955    // round 2's production set (register gathers): what the gather / neighbour-sum ablation masks are written for
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
@@ -1279,6 +1297,7 @@ hipError_t launch_fused_opt(A... args) {
     case 3955: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 3955>(args...);    // (A/B: round 2's production: register gathers)
     case 53107: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 53107>(args...);  // (A/B: ... + two units, counted waits)
     case 19827: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 19827>(args...);  // (A/B: production without the raised issue priority)
+    case 20339: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 20339>(args...);  // (A/B: round 3's production: no neighbour-sum fast path)
     case 85875: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 85875>(args...);  // (A/B: full-line gathers through staging registers)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }

@@ -350,18 +350,25 @@ struct PostParams {
   unsigned long long seed, offset;
 };
 
-// (No multiply-add contraction in the two posteriors: the reference evaluates them as separate fp32 torch operations, and
-// HIP's __fmul_rn / __fadd_rn are plain operators that hipcc's default -ffp-contract=fast may fuse - round 4 found the
-// Gaussian update off by one ulp of x_t on 0.6 % of the elements for that reason.)
+// No multiply-add contraction in the two posteriors: the reference evaluates them as separate fp32 torch operations.  HIP's
+// __fmul_rn / __fadd_rn are plain operators, hipcc's default -ffp-contract=fast fuses them in the backend whatever the source
+// says (a `#pragma clang fp contract(off)` is not honoured in that mode: checked in the ISA) - round 4 found the Gaussian update
+// off by one ulp of x_t on 0.6 % of the elements for that reason.  An empty asm that "modifies" the intermediate pins it.
+__device__ __forceinline__ float rounded(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the "v" constraint does not exist on the host pass)
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+
 __device__ __forceinline__ float categorical_step(float l0, float l1, float xt, const PostParams& pp, long long idx,
                                                   float* prob_out) {
-#pragma clang fp contract(off)
   const float m = fmaxf(l0, l1);
   const float e0 = expf(l0 - m), e1 = expf(l1 - m);
   const float den = e0 + e1;
   const float p0 = e0 / den, p1 = e1 / den;
   const int b = (int)xt >= 1 ? 1 : 0;      // x_t.long() (truncation, pl_meta_model.py:122); 0/1 inputs: the bit itself
-  const float prob = __fadd_rn(__fmul_rn(pp.p[b], p0), __fmul_rn(pp.p[2 + b], p1));
+  const float prob = rounded(pp.p[b] * p0) + rounded(pp.p[2 + b] * p1);
   if (prob_out) *prob_out = prob;
   if (pp.p[4] != 0.0f) {
     const float pc = fminf(fmaxf(prob, 0.0f), 1.0f);
@@ -376,13 +383,12 @@ __device__ __forceinline__ float categorical_step(float l0, float l1, float xt, 
 // gaussian: pl_meta_model.py:161-172.  post = {a, b, c, d, branch}: branch 0 (DDIM)
 //   x = a*(xt - b*pred) + c*pred ; branch 1 (DDPM) x = a*(xt - b*pred) + d*z.
 __device__ __forceinline__ float gaussian_step(float pred, float xt, const PostParams& pp, long long idx) {
-#pragma clang fp contract(off)
-  const float base = __fmul_rn(pp.p[0], __fsub_rn(xt, __fmul_rn(pp.p[1], pred)));
-  if (pp.p[4] == 0.0f) return __fadd_rn(base, __fmul_rn(pp.p[2], pred));
+  const float base = rounded(pp.p[0] * rounded(xt - rounded(pp.p[1] * pred)));
+  if (pp.p[4] == 0.0f) return base + rounded(pp.p[2] * pred);
   float z;
   if (pp.rand_mode == 1) z = pp.rand[idx];
   else z = philox_normal(pp.seed, pp.offset, (unsigned long long)idx);
-  return __fadd_rn(base, __fmul_rn(pp.p[3], z));
+  return base + rounded(pp.p[3] * z);
 }
 
 // head apply: GroupNorm affine -> ReLU -> 1x1 conv (C = 1 or 2) -> softmax/posterior/sample.
