@@ -52,10 +52,21 @@ def pmc_traffic_bytes(kernel_name, workload, n_edges, variant):
         if not entry:
             continue
         for key, val in entry.items():
-            if key in kernel_name:
-                return {"bytes_per_launch": val["fetch_bytes"] + val["write_bytes"], "fetch_bytes": val["fetch_bytes"],
-                        "write_bytes": val["write_bytes"],
-                        "source": f"profiles/{rnd}/pmc_traffic.json[{workload}:{n_edges}:{variant}] (rocprofv3 --pmc)"}
+            if key and key in kernel_name:
+                out = {"bytes_per_launch": val["fetch_bytes"] + val["write_bytes"], "fetch_bytes": val["fetch_bytes"],
+                       "write_bytes": val["write_bytes"],
+                       "source": f"profiles/{rnd}/pmc_traffic.json[{workload}:{n_edges}:{variant}] (rocprofv3 --pmc FETCH_SIZE x 1024 x 2 "
+                                 f"(gfx950 half-count correction) + WRITE_SIZE x 1024; memory-side (L2 -> fabric) requests: MALL hits "
+                                 f"are counted, no counter separates them from HBM)"}
+                # per level, when the L2 / EA passes were collected for this run (round 4): what the L2 saw and what left it
+                if "l2_read_requests_128B" in val:
+                    out["levels"] = {"l2_read_bytes": val["l2_read_requests_128B"] * 128.0, "l2_hits": val.get("l2_hits"),
+                                     "l2_misses": val.get("l2_misses"),
+                                     "ea_read_bytes": val.get("ea_read_bytes_128B_requests", 0.0) + val.get("ea_read_bytes_64B_requests", 0.0)
+                                     + val.get("ea_read_bytes_32B_requests", 0.0),
+                                     "ea_write_bytes": val.get("ea_write_bytes_64B_requests"),
+                                     "ea_read_latency_cycles": val.get("ea_read_latency_cycles")}
+                return out
     return None
 
 

@@ -331,6 +331,42 @@ hipError_t launch(const float* e, const unsigned short* planes, float* out, int 
 }  // namespace LAB_NS
 }  // namespace difusco
 
+#ifndef DIFUSCO_LAB_NOPK
+namespace difusco {
+namespace lab {
+// Re-read probe (where is the residual re-read of e served?): one pass over `n4` float4 with the cache policy of
+// the fused kernel's e accesses (aux 2 = non-temporal, 0 = default); the sum keeps the loads alive.  Timing pass 2 over a buffer
+// against pass 1 (cold) for buffer sizes around the re-use distance of the kernel tells whether the memory-side cache (MALL,
+// 256 MiB) serves a second read of lines that were streamed through the L2 non-temporally a few tens of microseconds earlier.
+template <int AUX>
+__global__ __launch_bounds__(256) void reread_probe_kernel(const float* __restrict__ buf, long long n4, float* __restrict__ sink) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(buf), 0, 0x7fffffff, 0x00020000);
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long base = (long long)blockIdx.x * blockDim.x; base < n4; base += stride) {
+    const long long i = base + threadIdx.x;
+    if (i < n4) {
+      const float* p = buf + i * 4;
+      v4f v;
+      if constexpr (AUX == 2) v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+      else v = *reinterpret_cast<const v4f*>(p);
+      acc += v;
+    }
+  }
+  (void)rs;
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 123456.789f) sink[0] = acc[0];
+}
+}  // namespace lab
+}  // namespace difusco
+extern "C" int difusco_lab_reread_pass(const float* buf, long long n_floats, int nontemporal, float* sink, void* stream) {
+  using namespace difusco::lab;
+  const long long n4 = n_floats / 4;
+  if (nontemporal) hipLaunchKernelGGL((reread_probe_kernel<2>), dim3(2048), dim3(256), 0, (hipStream_t)stream, buf, n4, sink);
+  else hipLaunchKernelGGL((reread_probe_kernel<0>), dim3(2048), dim3(256), 0, (hipStream_t)stream, buf, n4, sink);
+  return hipGetLastError() == hipSuccess ? DIFUSCO_OK : DIFUSCO_EHIP;
+}
+#endif
+
 extern "C" {
 // variant = EPW/32 * 100000 + WAVES * 10000 + NBUF * 1000 + SYNC * 100 + RING * 10 + PRIO; MINB follows from the geometry
 // (64-edge waves and 8-wave workgroups are one workgroup per CU, the production geometry two).  planes: the fp16 hi | lo

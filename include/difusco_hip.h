@@ -372,6 +372,9 @@ int difusco_debug_set_ptr(int key, void* p);
  * planes; do_store 0 = timing only; lds_pad = extra dynamic LDS bytes.  scripts/bench_stage_lab.py drives it. */
 int difusco_lab_gemm1(int variant, const float* e, const void* planes, float* out, int n_edges, float inv_c, int do_store,
                       int lds_pad, void* stream);
+/* Re-read probe: one streaming pass (float4 loads, non-temporal or default policy) over buf[0 .. n_floats); scripts/
+ * bench_reread_probe.py times a second pass over the same buffer against the first for several sizes. */
+int difusco_lab_reread_pass(const float* buf, long long n_floats, int nontemporal, float* sink, void* stream);
 /* the same translation unit compiled without packed fp32 arithmetic (target feature -packed-fp32-ops) */
 int difusco_lab_gemm1_nopk(int variant, const float* e, const void* planes, float* out, int n_edges, float inv_c, int do_store,
                            int lds_pad, void* stream);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/difusco_hip.h but not exported"
     assert L.difusco_abi_version() == _lib.ABI_VERSION
     # the profiling knobs (process-wide state, timing-only kernel variants) live in libdifusco_hip_prof.so only
-    assert prof_names == {"difusco_debug_set", "difusco_debug_set_ptr", "difusco_lab_gemm1", "difusco_lab_gemm1_nopk"}
+    assert prof_names == {"difusco_debug_set", "difusco_debug_set_ptr", "difusco_lab_gemm1", "difusco_lab_gemm1_nopk", "difusco_lab_reread_pass"}
     for n in prof_names:
         assert not hasattr(L, n), f"{n} must not be exported by the production library"
 
