@@ -1298,6 +1298,7 @@ hipError_t launch_fused_opt(A... args) {
     case 53107: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 53107>(args...);  // (A/B: ... + two units, counted waits)
     case 19827: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 19827>(args...);  // (A/B: production without the raised issue priority)
     case 20339: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 20339>(args...);  // (A/B: round 3's production: no neighbour-sum fast path)
+    case 150899: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 150899>(args...);  // (A/B: production without the raised issue priority)
     case 85875: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 85875>(args...);  // (A/B: full-line gathers through staging registers)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
