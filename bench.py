@@ -124,6 +124,22 @@ def cpu_baseline(wl, steps, params, gpu_model, device, warm=True):
         gpu = lambda x: gpu_model.categorical_denoise_step(x.to(device), np.array([t_chk]), device, ei.to(device),
                                                            target_t=np.array([tt_chk]), uniform=u, return_aux=True)
         what = f"1 graph ER-{n} p=0.15 ({ei.shape[1]} directed edges incl. self loops)"
+    elif wl.get("dense"):
+        V = wl["nodes"]
+        pts = torch.rand(1, V, 2, generator=g)
+        tab = O.CategoricalTables()
+        xt = (torch.randn(1, V, V, generator=g) > 0).float()
+        u = torch.rand(1, V, V, generator=g)
+        what = f"1 sample dense TSP-{V} ({V * V} edges)"
+
+        def step(xt, t1, t2, **kw):
+            r = O.tsp_categorical_denoise_step(params, tab, pts, xt, t1, None, t2, **kw)
+            if isinstance(r, tuple):      # logits [B,2,V,V] -> [B,V,V,2] (the layout the HIP path returns)
+                return (r[0], r[1].permute(0, 2, 3, 1).contiguous(), r[2])
+            return r
+        gpu = lambda x: gpu_model.categorical_denoise_step(pts.to(device), x.to(device), np.array([t_chk]), device, None,
+                                                           target_t=np.array([tt_chk]), uniform=u.reshape(-1), return_aux=True)
+        ei = None
     else:
         pts, ei = tsp_instance(wl["nodes"], wl["knn"], seed=1000)
         pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
@@ -159,8 +175,8 @@ def cpu_baseline(wl, steps, params, gpu_model, device, warm=True):
                 if u is not None:
                     pr = res[2].reshape(-1)
                     parity["parity_prob_linf"] = float((got[2].cpu().reshape(-1) - pr).abs().max())
-                    safe = (u - pr).abs() > 1e-4
-                    parity["parity_bits_equal"] = bool(torch.equal(got[0].cpu()[safe], res[0][safe]))
+                    safe = (u.reshape(-1) - pr).abs() > 1e-4
+                    parity["parity_bits_equal"] = bool(torch.equal(got[0].cpu().reshape(-1)[safe], res[0].reshape(-1)[safe]))
                 else:
                     parity["parity_xt_linf"] = float((got[0].cpu() - res[0]).abs().max())
                 parity["parity_what"] = (f"network output of step (t={t1} -> {t2}) of that graph, HIP path (default engine) vs "
@@ -185,6 +201,9 @@ WORKLOADS = {
     "tsp500": dict(task="tsp", diffusion="categorical", nodes=500, knn=50, graphs_per_gpu=16),
     "tsp10000": dict(task="tsp", diffusion="gaussian", nodes=10000, knn=100, graphs_per_gpu=1),
     "mis": dict(task="mis", diffusion="categorical", nodes=None, knn=None, graphs_per_gpu=16),
+    # BASELINE configs[0]'s model (dense TSP-50, no k-NN sparsification) with 16 parallel samples in one call: per-sample GroupNorm
+    # statistics (gnn_encoder.py:380), complete-graph CSR, fused layers since round 4
+    "tsp50dense": dict(task="tsp", diffusion="categorical", nodes=50, knn=None, graphs_per_gpu=16, dense=True),
 }
 
 
@@ -236,7 +255,7 @@ def main():
                     "torch.ops.difusco.* (csrc/torch_ops.cpp; the default) or ctypes (the default with the profiling library)")
     ap.add_argument("--no-prepare", action="store_true", help="A/B: recompute the step-invariant part of a TSP step (node "
                     "embedding, layer-0 node linear, time-bias rows) in every step instead of once per (graph, schedule)")
-    ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of each `workloads` entry (2 warm-up steps)")
+    ap.add_argument("--sub-steps", type=int, default=10, help="timed steps of each `workloads` entry (4 warm-up steps; three repetitions)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -289,9 +308,9 @@ def main():
         # (live HIP events), one oracle step on one graph with the parity of that step.  Headline fields stay TSP-1000.
         if world == 1 and not dry and not args.no_workloads and args.workload == "tsp1000" and args.streams == 1:
             out["workloads"] = {}
-            for name in ("tsp500", "tsp10000", "mis"):
+            for name in ("tsp500", "tsp10000", "mis", "tsp50dense"):
                 t0 = time.perf_counter()
-                sub = measure(args, name, args.sub_steps, 2, 1, False, rank, world, device, dry, step_flags, dist, overrides=False)
+                sub = measure(args, name, args.sub_steps, 4, 1, False, rank, world, device, dry, step_flags, dist, overrides=False)
                 keep = {k: sub[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "repeats") if k in sub}
                 for k in ("roofline", "cpu_baseline", "parity_linf"):
                     if k in sub:
@@ -314,7 +333,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
             if getattr(args, key) is not None:
                 wl[key] = getattr(args, key)
     nodes, knn, graphs_per_gpu = wl["nodes"], wl["knn"], wl["graphs_per_gpu"]
-    gaussian, mis = wl["diffusion"] == "gaussian", wl["task"] == "mis"
+    gaussian, mis, dense = wl["diffusion"] == "gaussian", wl["task"] == "mis", bool(wl.get("dense"))
     from difusco_amd.dist import engine_from_broadcast, gn_allreduce, shard_range
     from difusco_amd.engine import DenoiseEngine
     from difusco_amd.models import MISModel, TSPModel
@@ -342,7 +361,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion, flags=step_flags,
                                backend=args.backend)
     margs = dict(diffusion_type=wl["diffusion"], diffusion_schedule="linear", diffusion_steps=1000,
-                 inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=knn if not mis else -1,
+                 inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=knn if not (mis or dense) else -1,
                  n_layers=LAYERS, hidden_dim=H, inference_trick="ddim")
     gn_reduce = gn_allreduce() if (args.gn_stats == "global" and world > 1) else None
     if dry:
@@ -376,6 +395,11 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         points, edge_index = None, torch.from_numpy(np.concatenate(eis, 1)).to(device)
         N_local = n_off
         xt = (torch.randn(N_local, generator=gen) > 0).float().to(device)
+    elif dense:
+        points = torch.rand(hi - lo, nodes, 2, generator=gen).to(device)
+        edge_index = None
+        N_local = (hi - lo) * nodes
+        xt = (torch.randn(hi - lo, nodes, nodes, generator=gen) > 0).float().to(device)
     else:
         if dry:
             from difusco_amd.synthetic import tsp_batch
@@ -386,7 +410,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         xt = torch.randn(edge_index.shape[1], generator=gen)
         xt = (xt if gaussian else (xt > 0).float()).to(device)
     G_local = hi - lo
-    E_local = edge_index.shape[1]
+    E_local = edge_index.shape[1] if edge_index is not None else (hi - lo) * nodes * nodes
     sched = InferenceSchedule("cosine", T=1000, inference_T=50)
 
     def one_step(i, xt, mdl=None):
@@ -494,7 +518,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         value = G_total * steps / dt
         out = {
             "metric": ("PLUMBING DRY RUN, NO KERNEL RAN - " if dry else "") + "denoising steps/sec (graphs x steps / s), " + (
-                "MIS ER-[700,800] sparse categorical" if mis else
+                "MIS ER-[700,800] sparse categorical" if mis else f"TSP-{nodes} dense {wl['diffusion']}" if dense else
                 f"TSP-{nodes} k-NN sparse {wl['diffusion']}"),
             "value": value, "unit": "graph-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
@@ -510,7 +534,8 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
             "prepare_ms_per_sampling_run": prepare_ms,
             "ranks_seen": ranks_seen, "rank_ms_per_step": rank_ms, "broadcast_ms": broadcast_ms,
             "config": {"workload": (f"MIS Erdos-Renyi n~U[700,800] p=0.15 (+reverse edges, +self loops) sparse categorical"
-                                    if mis else f"TSP-{nodes} k-NN K={knn} sparse {wl['diffusion']}") +
+                                    if mis else f"TSP-{nodes} dense (complete graph, one GroupNorm statistic segment per sample) {wl['diffusion']}"
+                                    if dense else f"TSP-{nodes} k-NN K={knn} sparse {wl['diffusion']}") +
                                    f", cosine 50-step schedule, {graphs_per_gpu} graphs per GPU "
                                    f"(global batch {G_total}), H={H}, {LAYERS} layers",
                        "name": workload, "graphs_per_gpu": graphs_per_gpu, "global_batch": G_total,
@@ -533,7 +558,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
             # fused: both E-row GEMMs of a layer in one launch.  The first layer of a table-input step (categorical TSP,
             # MIS) has no GEMM 1 and reads no e; the last layer of a MIS step has no GEMM 2 and writes no e: the
             # per-launch averages below account for that (12 launches per step).
-            first_light = fused and not args.no_l0_fold and (mis or not gaussian)
+            first_light = fused and not args.no_l0_fold and (mis or not gaussian)      # (dense TSP categorical included)
             last_light = fused and not args.no_gn_fold and mis and LAYERS >= 2
             gemms = (2.0 * LAYERS - first_light - last_light) / LAYERS if fused else 1.0
             passes = (2.0 * LAYERS - first_light - last_light) / LAYERS if fused else 2.5

@@ -16,6 +16,17 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _op_call(fn, *args):
+    """A ``torch.ops.difusco.*`` call with the error type of the ctypes binding: the shim reports a failing C entry point as
+    ``RuntimeError("libdifusco_hip <entry> failed (<code>): <message>")``; both bindings raise ``DifuscoHipError`` for it."""
+    try:
+        return fn(*args)
+    except RuntimeError as exc:
+        if "libdifusco_hip " in str(exc):
+            raise _lib.DifuscoHipError(str(exc).split("\n")[0]) from None
+        raise
+
+
 class DenoiseEngine:
     def __init__(self, state_dict=None, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
                  fused: bool = True, backend: Optional[str] = None, flags: int = 0, config=None):
@@ -93,7 +104,7 @@ class DenoiseEngine:
         if not todo:
             return
         if self.backend == "torch":
-            out = self._ops.time_bias_rows(self.blob, todo, self._cfg())
+            out = _op_call(self._ops.time_bias_rows, self.blob, todo, self._cfg())
         else:
             out = torch.empty((len(todo), self.n_layers, self.hidden), dtype=torch.float32, device=self.device)
             arr = (ctypes.c_float * len(todo))(*todo)
@@ -119,7 +130,7 @@ class DenoiseEngine:
             pts = pts.reshape(-1, 2).index_select(0, g.node_order)
         ws = self._workspace(g)
         if self.backend == "torch":
-            return self._ops.prepare_state(self.blob, pts, g.n_nodes, g.n_edges, g.n_segments, ws, self._cfg())
+            return _op_call(self._ops.prepare_state, self.blob, pts, g.n_nodes, g.n_edges, g.n_segments, ws, self._cfg())
         need = _lib.lib().difusco_prepared_bytes(self.hidden, g.n_nodes)
         buf = torch.empty(need, dtype=torch.uint8, device=self.device)
         a = _lib.StepArgs()
@@ -235,8 +246,8 @@ class DenoiseEngine:
 
         def call(phase, sums):
             cfg[7] = phase
-            return op(self.blob, g.rowptr, g.col, g.perm, g.row, seg, points, xt, float(t), post, rand, seed, offset, ws, cfg,
-                      want_pred, want_prob, sums, prepared, tbias)
+            return _op_call(op, self.blob, g.rowptr, g.col, g.perm, g.row, seg, points, xt, float(t), post, rand, seed, offset, ws,
+                            cfg, want_pred, want_prob, sums, prepared, tbias)
         if gn_reduce is None:
             out = call(0, None)
         else:
