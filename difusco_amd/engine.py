@@ -77,19 +77,23 @@ class DenoiseEngine:
                     f"backend='torch' launches through {LIB_PATH}, but ctypes loaded {_lib.loaded_path()}: "
                     "use backend='ctypes' with the profiling library / DIFUSCO_HIP_LIBRARY")
             self._ops = torch_ops.load()
-        self._ws = None
+        self._ws = {}               # HIP stream -> workspace tensor
         self._tbias = {}            # t -> [n_layers, hidden] time-bias rows on the device (prepare_times / lazily per t)
         self.calls = 0
 
     # ---- workspace -----------------------------------------------------------------------------
     def _workspace(self, g: CsrGraph) -> torch.Tensor:
+        """The scratch buffer of a step, one per HIP stream the engine is used on (steps on different streams may overlap; a
+        step owns its workspace from launch to completion, so two streams must not share one)."""
         need = _lib.lib().difusco_workspace_bytes(self.hidden, self.n_layers, g.n_nodes, g.n_edges, g.n_segments)
         if need == 0:
             raise _lib.DifuscoHipError("difusco_workspace_bytes rejected the problem shape")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws.pop(key, None)
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
 
     def _cfg(self, task: int = _lib.TASK_TSP, xt_is_binary: bool = False, phase: int = 0):
         """cfg list of the torch ops: {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}"""

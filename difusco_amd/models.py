@@ -143,9 +143,10 @@ class COMetaModel:
         if self.prepare:
             self.model.prepare_times([_as_int(t) for t in times])
 
-    def duplicate_edge_index(self, edge_index, num_nodes, device):
-        """Disjoint union of ``parallel_sampling`` replicas (pl_meta_model.py:177-184)."""
-        P = self.args.parallel_sampling
+    def duplicate_edge_index(self, edge_index, num_nodes, device, copies: Optional[int] = None):
+        """Disjoint union of ``parallel_sampling`` replicas (pl_meta_model.py:177-184).  ``copies`` (extension): the number of
+        replicas, instead of ``self.args.parallel_sampling`` - callers need not write to the args to ask for a batch."""
+        P = self.args.parallel_sampling if copies is None else int(copies)
         shift = torch.arange(0, P, device=device).view(1, -1, 1) * num_nodes
         return (edge_index.reshape((2, 1, -1)).to(device) + shift).reshape((2, -1))
 

@@ -52,10 +52,9 @@ def solve_tsp(model, points: np.ndarray, sparse_factor: int, parallel_sampling: 
     pts32 = torch.from_numpy(pts64.astype(np.float32)).to(dev)
     np_points = pts32.cpu().numpy()
     np_points64 = np_points.astype(np.float64)
-    model.args.parallel_sampling = parallel_sampling    # duplicate_edge_index reads it from the args, like the reference
     if sparse:
         pts_rep = pts32.repeat(parallel_sampling, 1)                                        # :178-183
-        ei_rep = model.duplicate_edge_index(edge_index, n, dev) if parallel_sampling > 1 else edge_index
+        ei_rep = model.duplicate_edge_index(edge_index, n, dev, copies=parallel_sampling) if parallel_sampling > 1 else edge_index
     else:
         pts_rep, ei_rep = pts32.reshape(1, n, 2).repeat(parallel_sampling, 1, 1), None
 
@@ -95,8 +94,7 @@ def solve_mis(model, n_nodes: int, edge_index, parallel_sampling: int = 1, gener
     ei = edge_index if isinstance(edge_index, torch.Tensor) else torch.from_numpy(np.asarray(edge_index))
     ei = ei.to(dev)
     tick = _ticker(timings, dev)
-    model.args.parallel_sampling = parallel_sampling
-    ei_rep = model.duplicate_edge_index(ei, n_nodes, dev) if parallel_sampling > 1 else ei        # pl_mis_model.py:168-169
+    ei_rep = model.duplicate_edge_index(ei, n_nodes, dev, copies=parallel_sampling) if parallel_sampling > 1 else ei   # pl_mis_model.py:168-169
     graph = model.prepare_graph(ei_rep, n_nodes * parallel_sampling)
     sols = []
     for _ in range(sequential_sampling):                                                          # :156
