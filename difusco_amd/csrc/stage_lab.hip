@@ -19,6 +19,12 @@
 //   PRIO  1: s_setprio 1 around every MFMA group
 //   MINB  workgroups per CU the register budget is sized for (__launch_bounds__ second argument): 2 -> <= 256 registers,
 //         1 -> up to 512 (one wave per SIMD with 4-wave workgroups)
+//   VMIX  synthetic EPILOGUE of the size of the fused kernel's (per 32-edge tile and lane 128 elements x 2 rounds of {fma, exp2,
+//         add, rcp, mul, fma, max, add}: 2,048 vector + 512 transcendental instructions, 256 LDS operations on a wave-private
+//         scratch), to measure how such work overlaps a GEMM.  1: SERIAL - after the 16 stages, on the tile's own accumulators (the
+//         production structure: a wave alternates matrix and vector phases, two waves per SIMD overlap by chance).  2:
+//         INTERLEAVED - one 64th of the epilogue of ANOTHER tile (an independent register array) behind every MFMA group of the
+//         GEMM, one wave per SIMD (the hand-scheduled structure of DESIGN section 7 (c))
 #include "edge_layer_common.h"
 
 #ifdef DIFUSCO_PROFILING
@@ -85,7 +91,7 @@ __device__ __forceinline__ void lab_flags_wait(volatile int* f, int need) {
   }
 }
 
-template <int EPW, int WAVES, int NBUF, int SYNC, int RING, int PRIO, int MINB, int DIST>
+template <int EPW, int WAVES, int NBUF, int SYNC, int RING, int PRIO, int MINB, int DIST, int VMIX>
 __global__ __launch_bounds__(64 * WAVES, MINB) void stage_lab_kernel(const float* __restrict__ e,
                                                                      const unsigned short* __restrict__ c_planes,
                                                                      long long plane_stride, float* __restrict__ out,
@@ -170,6 +176,36 @@ __global__ __launch_bounds__(64 * WAVES, MINB) void stage_lab_kernel(const float
 
   const int a_off = wslot(l31, hh);
 
+  // synthetic epilogue (VMIX): element = {fma, exp2, add, rcp, mul, fma, max, add} twice; LDS round trips on the wave's scratch
+  float* lscr = reinterpret_cast<float*>(smem_raw + NBUF * BUF * 2 + 256) + wave * 64 * 20 + lane * 4;
+  const float ca = 1.0009765625f, cb = 0.03125f, cc = -1.4426950408889634f, cg = 0.998046875f, ct = 0.015625f;
+#define LAB_ELEM(x)                                                                                  \
+  {                                                                                                  \
+    _Pragma("unroll") for (int rnd_ = 0; rnd_ < 2; ++rnd_) {                                         \
+      const float z_ = __builtin_fmaf((x), ca, cb);                                                  \
+      const float s_ = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z_ * cc));                \
+      float y_ = __builtin_fmaf(z_ * s_, cg, cb);                                                    \
+      (x) = __builtin_fmaxf(y_, 0.0f) + ct;                                                          \
+    }                                                                                                \
+  }
+  // chunk c (0..63) of an epilogue over the 128 values v[0..127]: two elements + 4 LDS operations
+#define LAB_CHUNK(v, c)                                                                              \
+  {                                                                                                  \
+    LAB_ELEM(v[2 * (c)])                                                                             \
+    LAB_ELEM(v[2 * (c) + 1])                                                                         \
+    *reinterpret_cast<v4f*>(lscr + ((c) & 3) * 256 * 0) = v4f{v[2 * (c)], v[2 * (c) + 1], 0.f, 0.f}; \
+    const v4f r_ = *reinterpret_cast<const v4f*>(lscr);                                              \
+    v[2 * (c)] += r_[2];                                                                             \
+    *reinterpret_cast<v4f*>(lscr) = v4f{v[2 * (c) + 1], v[2 * (c)], 0.f, 0.f};                       \
+    const v4f q_ = *reinterpret_cast<const v4f*>(lscr);                                              \
+    v[2 * (c) + 1] += q_[3];                                                                         \
+  }
+  float ex[VMIX == 2 ? 128 : 1];
+  if constexpr (VMIX == 2) {
+#pragma unroll
+    for (int i = 0; i < 128; ++i) ex[i] = er[0][0][0][i & 3] * (float)(i + 1);
+  }
+
   // first stage landed (every wave's pieces)
   if constexpr (SYNC == 2) {
     wait_vmcnt<(DIST - 1) * PPW>();
@@ -243,6 +279,7 @@ __global__ __launch_bounds__(64 * WAVES, MINB) void stage_lab_kernel(const float
         acc[u][n1] = T::mfma(fh[s1], xh[u], acc[u][n1]);
       }
       if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
+      if constexpr (VMIX == 2) { LAB_CHUNK(ex, 4 * t + bp) }
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef LAB_FRAG
@@ -285,6 +322,21 @@ __global__ __launch_bounds__(64 * WAVES, MINB) void stage_lab_kernel(const float
   }
 #undef LAB_DMA_STAGE
 #undef LAB_E_LOAD
+  if constexpr (VMIX == 1) {      // the tile's own accumulators: 128 values per lane
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+      float* v = reinterpret_cast<float*>(&acc[0][c >> 3]) + 2 * (c & 7) - 2 * c;      // v[2c], v[2c+1] = the pair c of block c / 8
+      LAB_CHUNK(v, c)
+    }
+  }
+  if constexpr (VMIX == 2) {      // keep the interleaved epilogue alive
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 128; ++i) sum += ex[i];
+    if (sum == 123456.789f) out[0] = sum;
+  }
+#undef LAB_CHUNK
+#undef LAB_ELEM
 
   // out (tiled like e) = acc / 2^kc
   if (do_store) {
@@ -313,17 +365,17 @@ __global__ __launch_bounds__(64 * WAVES, MINB) void stage_lab_kernel(const float
   }
 }
 
-template <int EPW, int WAVES, int NBUF, int SYNC, int RING, int PRIO, int MINB, int DIST = NBUF - 1>
+template <int EPW, int WAVES, int NBUF, int SYNC, int RING, int PRIO, int MINB, int DIST = NBUF - 1, int VMIX = 0>
 hipError_t launch(const float* e, const unsigned short* planes, float* out, int n_edges, float inv_c, int do_store,
                   int lds_pad, hipStream_t st) {
   static std::atomic<unsigned long long> attr_devices{0};
   hipError_t er = ensure_max_dynamic_lds(
-      attr_devices, reinterpret_cast<const void*>(&stage_lab_kernel<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST>), 160 * 1024);
+      attr_devices, reinterpret_cast<const void*>(&stage_lab_kernel<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST, VMIX>), 160 * 1024);
   if (er != hipSuccess) return er;
   const int per_wg = EPW * WAVES;
   if (n_edges % per_wg != 0) return hipErrorInvalidValue;
-  const int lds = NBUF * BUF * 2 + 256 + lds_pad;
-  hipLaunchKernelGGL((stage_lab_kernel<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST>), dim3((unsigned)(n_edges / per_wg)),
+  const int lds = NBUF * BUF * 2 + 256 + WAVES * 64 * 20 * 4 + lds_pad;      // stage buffers | flags | VMIX scratch
+  hipLaunchKernelGGL((stage_lab_kernel<EPW, WAVES, NBUF, SYNC, RING, PRIO, MINB, DIST, VMIX>), dim3((unsigned)(n_edges / per_wg)),
                      dim3(64 * WAVES), lds, st, e, planes, (long long)H * H, out, n_edges / 32, inv_c, do_store);
   return hipGetLastError();
 }
@@ -404,6 +456,11 @@ int LAB_ENTRY(int variant, const float* e, const void* planes, float* out, int n
     LAB_CASE(184120, 32, 8, 4, 1, 2, 0, 1)
     LAB_CASE(184121, 32, 8, 4, 1, 2, 1, 1)
     LAB_CASE_D(184220, 32, 8, 4, 2, 2, 0, 1, 2)
+    // synthetic epilogue (VMIX): serial at two waves per SIMD | interleaved behind the MFMA groups at one wave per SIMD | serial at one wave per SIMD
+    case 1142020: er = launch<32, 4, 2, 0, 2, 0, 2, 1, 1>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
+    case 2142020: er = launch<32, 4, 2, 0, 2, 0, 1, 1, 2>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
+    case 2143120: er = launch<32, 4, 3, 1, 2, 0, 1, 2, 2>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
+    case 3142020: er = launch<32, 4, 2, 0, 2, 0, 1, 1, 1>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
     default: return difusco::set_error(DIFUSCO_EINVAL, "unknown lab variant %d", variant);
   }
 #undef LAB_CASE

@@ -55,6 +55,10 @@ for v in variants:
     out.zero_()
     run(v, 1)
     torch.cuda.synchronize()
+    code = int(v.rstrip("n"))
+    if code >= 1_000_000 and code // 1_000_000 != 2:      # VMIX 1 / 3: the synthetic epilogue rewrites the accumulators (timing only)
+        ok[v] = None
+        continue
     got = graph.from_tiled(out, E)[ref_rows.to(dev)].cpu().double()
     err = float((got - ref).abs().max())
     ok[v] = err
