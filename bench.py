@@ -617,9 +617,9 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
                     "edge_linear": {"ms_total": prof["ms"][0], "launches": prof["launches"][0]},
                     "node_linear": {"ms_total": prof["ms"][1], "launches": prof["launches"][1]},
                     "edge_gate_aggregate": {"ms_total": prof["ms"][2], "launches": prof["launches"][2],
-                                            "achieved_GBs": gate_bytes / g_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
-                                            "frac": gate_bytes / g_s / 1e9 / PEAK_HBM_GBS, "bound": "hbm",
-                                            "algorithmic_bytes_per_launch": gate_bytes},
+                                            **({"achieved_GBs": gate_bytes / g_s / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                                                "frac": gate_bytes / g_s / 1e9 / PEAK_HBM_GBS} if g_s > 0 else {}),      # (--profile-all)
+                                            "bound": "hbm", "algorithmic_bytes_per_launch": gate_bytes},
                 }
             out["kernels"]["profiled"] = ("every launch (--profile-all)" if args.profile_all else
                                           "dominant kernel only; the other entries are empty (use --profile-all)")
