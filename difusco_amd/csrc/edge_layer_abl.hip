@@ -18,6 +18,10 @@ hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS) {
     case 17: return launch_fused_t<FFp16, 15, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // 15 with the production options
     case 18: return launch_fused_t<FFp16, 16, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // 16 (phase stamps), production options (full-line gathers)
     case 19: return launch_fused_t<FFp16, 16, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // stamps, round 2's options (register gathers)
+    case 34: return launch_fused_t<FFp16, 16 + 1024, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // stamps, gather requests never waited for
+    case 35: return launch_fused_t<FFp16, 16 + 1024 + 2048, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // stamps, no gather requests, no waits
+    case 36: return launch_fused_t<FFp16, 1024, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // (no stamps) gather requests never waited for
+    case 37: return launch_fused_t<FFp16, 1024 + 2048, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // (no stamps) no gather requests, no waits
     case 22: return launch_fused_t<FFp16, 16 + 32768, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // stamps, no e stream
     case 23: return launch_fused_t<FFp16, 16 + 16384, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // stamps, no stage refills / barriers
     case 24: return launch_fused_t<FFp16, 16 + 1, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);       // stamps, no gathers

@@ -607,6 +607,8 @@ _Pragma("unroll")                                                               
   // A(nb + 1) requested, the messages formed.  Every wait is vmcnt(0): stores share the counter on gfx9.
   constexpr bool kFL = (OPT & 16384) != 0;
   static_assert(!kFL || (kPk && (ablate & 0x3EF) == 0 && !kG2), "OPT bit 14 is written for the production arithmetic");
+  // ABL 1024 / 2048 (profiling library, wrong results): the full-line gather requests are issued but never waited for / not
+  // issued at all - what the waits and what the issue of the 64 LDS-DMA pieces cost in the gather phase
   // OPT bit 15 (with bit 14): TWO units - A in the wave's share of buffer 1, V in its share of buffer 0 - so that the next block
   // of a table is requested as soon as the current one has been read (a whole block of cover instead of half).  Buffer 0 is
   // free because GEMM 2's first weight stage is then requested AFTER the gather phase (kLate16; the LayerNorm phase covers it)
@@ -728,14 +730,16 @@ _Pragma("unroll")                                                               
     for (int g = 0; g < 4; ++g) rd_pos[g] = ((2 * g + hh) ^ swz(l31)) * 16;
     // table: 1 = V (float offset H), 2 = A (float offset 2 H) of the node4 row; unit 0 = buffer 1 areas, 1 = buffer 0 areas
 #define FUSED_FL_REQUEST(table, nb_, unit)                                                                                  \
-  {                                                                                                                       \
+  if constexpr ((ABL & 2048) == 0) {      /* (ABL 2048: timing only - no gather requests at all: stale LDS is read) */     \
     _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4)                                                                      \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_n,                                                                      \
           (__attribute__((address_space(3))) void*)(((unit) ? ((p4 >> 1) ? ub1 : ub0) : ((p4 >> 1) ? ua1 : ua0)) + (p4 & 1) * 512), \
           16, src_off[p4], (table) * H * 4 + (nb_) * 128, 0, 0);                                                          \
   }
 #define FUSED_FL_WAIT(n)                                                          \
-  __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14));           \
+  if constexpr ((ABL & 1024) == 0) {      /* (ABL 1024: timing only - the gather requests are never waited for) */ \
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14));         \
+  }                                                                               \
   __builtin_amdgcn_sched_barrier(0);                                              \
   asm volatile("" ::: "memory");
 #define FUSED_FL_READ(dst, unit)                                                                      \
