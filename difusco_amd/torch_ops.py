@@ -6,10 +6,14 @@ The ops are a thin C++ shim (``csrc/torch_ops.cpp``, ``TORCH_LIBRARY(difusco, ..
     torch.ops.difusco.prepare_graph(edge_index_cpu, n_nodes)      -> rowptr, col, row, perm, identity   (host)
     torch.ops.difusco.weights_layout(hidden, n_layers, C)          -> int64 offsets (+ total)
     torch.ops.difusco.workspace_bytes(hidden, n_layers, N, E, S)   -> int
+    torch.ops.difusco.prepare_state(blob, points, N, E, S, workspace, cfg) -> uint8 buffer;  time_bias_rows(blob, times, cfg) -> [n_t, L, H]
     torch.ops.difusco.denoise_step_categorical(...) / denoise_step_gaussian(...) -> (xt_next, pred, prob)
 
-``DenoiseEngine(..., backend="torch")`` (and the models' ``backend=`` argument) routes every step through these ops
-instead of ctypes; both paths launch the same kernels on the current stream and are bitwise identical (GPU test)."""
+These ops are the DEFAULT binding of ``DenoiseEngine`` / ``TSPModel`` / ``MISModel`` (``backend=None``); ``backend="ctypes"`` routes
+through ctypes instead (and is chosen automatically with the profiling library / a ``DIFUSCO_HIP_LIBRARY`` build, because the shim is
+linked against the production library).  Both launch the same kernels on the current stream, are bitwise identical (GPU tests) and
+equally fast (profiles/r04/bench_binding_ab.txt).  ``prepare_state`` / ``time_bias_rows`` are the ops of the optional prepared state
+(include/difusco_hip.h: ``difusco_prepare``, ``difusco_time_bias_rows``)."""
 import os
 
 import torch
