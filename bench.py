@@ -87,6 +87,24 @@ def pmc_pipe_busy(workload, n_edges, variant, avg_launch_s, n_simd=1024, clock_h
                       f"({n_simd} SIMDs x live avg launch x 2.4 GHz)"}
 
 
+def power_limited_mfma(mfma_tf_issued, precision):
+    """The matrix rate the part sustains on THIS kind of data: GEMM 1 of the fused layer alone, on N(0,1) operands, sits at
+    the 1,400 W socket cap with the engine clock held at 1.43 GHz (profiles/r04/lab_power.json, lab_power_randn_vs_zeros.txt:
+    the same instruction stream on zeroed operands runs 43 % faster at 2.07 GHz).  Reported beside `frac_issued`; `peak`
+    stays the nominal dense peak."""
+    if precision != "fp16x3":
+        return None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r04", "lab_power.json")))
+        tf = float(rec["randn"]["mfma_TFLOPs_issued"])
+    except (OSError, ValueError, KeyError):
+        return None
+    return {"gemm_only_TFLOPs_issued": tf, "frac_of_nominal_peak": tf / PEAK_BF16_MFMA_TFLOPS,
+            "frac_issued_of_power_limited": mfma_tf_issued / tf, "power_cap_W": rec.get("power_cap_W"),
+            "power_W": rec["randn"].get("power_W_median"), "sclk_MHz": rec["randn"].get("sclk_MHz_median"),
+            "source": "profiles/r04/lab_power.json (scripts/bench_lab_power.py: GEMM 1 alone, fp16x3, N(0,1) operands, rocm-smi beside it)"}
+
+
 def oracle_threads():
     """torch threads for the CPU-oracle leg.  Measured on the GPU box's host (2 x EPYC 9575F, 128 physical cores,
     profiles/r02/cpu_threads_scan.txt, one TSP-1000 step): 16 threads 4.8 s, 32 threads 4.2 s, 64 threads 5.7 s,
@@ -598,6 +616,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
                                     "frac_algorithmic": alg_tf / mfma_peak,
                                     "mfma_TFLOPs_issued": mfma_tf, "frac_issued": mfma_tf / mfma_peak,
                                     "pipe_busy": pmc_pipe_busy(workload, E_local, variant, avg_s),
+                                    "power_limited_mfma": power_limited_mfma(mfma_tf, args.precision) if fused else None,
                                     "frac_fp32_mfma_peak": alg_tf / PEAK_FP32_MFMA_TFLOPS,
                                     "hbm_GBs_algorithmic": hbm_gbs, "hbm_frac_of_8TBs": hbm_gbs / PEAK_HBM_GBS,
                                     "other_ms_per_step": 1e3 * dt / steps - avg_s * 1e3 * n_lin / (steps * repeats)})

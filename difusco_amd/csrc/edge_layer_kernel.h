@@ -130,6 +130,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //   bit 14 FULL-LINE neighbour-table gathers through LDS-DMA (+3.4 %, see the gather phase), bit 15 two units + counted waits (no
   //          further gain, profiling library only).
   //   bit 17 neighbour-sum fast path for tiles with one centre node (round 4, bit-identical).
+  //   bit 18 16-bit planes of a product straight from its factors (round 4; 256 vector instructions fewer per tile and 1.2 %
+  //          SLOWER, see kMixSplit; profiling library / build variant only).
   // Production = 151411 (bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14, 17).  Bits 0-11 = 3955: +16 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
   // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5, 8-10 do not change a result bit; bit 6
@@ -411,6 +413,14 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // stage then ends with vmcnt(2) instead of vmcnt(0): the weight pieces have landed (requests complete in order), the
   // e loads stay in flight across the barrier and are waited for at the end of the NEXT stage.
   constexpr bool kDeepE = (OPT & 32) != 0;
+  // OPT bit 18: the 16-bit planes of a PRODUCT straight from its two factors (T::split_pair_mul: four v_fma_mix{lo,hi}_f16 per
+  // pair instead of two multiplies + the six-instruction split) - the scaled e slabs of GEMM 1 (bit-identical) and the
+  // activation z sigmoid(z) of GEMM 2 (the product is no longer rounded to fp32 before the split: last bit of the lo plane).
+  // 256 of the kernel's ~5,100 vector instructions per tile - and measured SLOWER (same box, 3 + 3 interleaved runs, profiles/r04/
+  // exp_mix_split.txt): TSP-1000 0.7598 vs 0.7493 ms per launch, MIS 1.182 vs 1.171, TSP-500 0.402 vs 0.400, TSP-10000 equal.
+  // The count of vector instructions is not what the epilogue costs; the half-register writes chain (mixhi waits for mixlo)
+  // and every group of them draws a wait state.  Not in the production set.
+  constexpr bool kMixSplit = (OPT & 262144) != 0;
   static_assert(!kDeepE || (SPS == 1 && RING == 2), "OPT bit 5 is written for the 16 KiB stages");
 #pragma unroll
   for (int t = 0; t < (L0 ? 0 : NS1); ++t) {
@@ -429,12 +439,18 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           er[ks % RING][1] = ld_e(((ks + RING) * 512 + 256), kBufRing);
         }
       }
-      if constexpr (T::kScaled) {
-        c0 = c0 * sx;
-        c1 = c1 * sx;
+      if constexpr (kMixSplit && T::kScaled) {      // scale and split in one go (bit-identical planes: the scale is a power of two)
+        const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float ms[8] = {sx, sx, sx, sx, sx, sx, sx, sx};
+        split8_mul<T>(xs, ms, xh[sub], xl[sub]);
+      } else {
+        if constexpr (T::kScaled) {
+          c0 = c0 * sx;
+          c1 = c1 * sx;
+        }
+        const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        split8<T>(xs, xh[sub], xl[sub]);
       }
-      const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-      split8<T>(xs, xh[sub], xl[sub]);
     }
     if constexpr (kDeepE) {
       __builtin_amdgcn_sched_barrier(0);
@@ -1033,7 +1049,7 @@ _Pragma("unroll")                                                               
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) {
-      float a8[8];
+      float a8[8], m8[8];      // (m8: kMixSplit - the activation is a8 * m8, multiplied inside the split)
 #pragma unroll
       for (int g2 = 0; g2 < 2; ++g2) {
         const int g = 2 * rg + g2;
@@ -1044,9 +1060,17 @@ _Pragma("unroll")                                                               
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
             const v2f z = DIFUSCO_PAIR(acc1[nb], 4 * g + 2 * h2) * v2f{rstd2, rstd2} * DIFUSCO_PAIR(go, 2 * h2) + DIFUSCO_PAIR(bo, 2 * h2);
-            const v2f a = z * fast_sigmoid2s(z, nsig);
-            a8[4 * g2 + 2 * h2] = a[0];
-            a8[4 * g2 + 2 * h2 + 1] = a[1];
+            if constexpr (kMixSplit) {
+              const v2f sg = fast_sigmoid2s(z, nsig);
+              a8[4 * g2 + 2 * h2] = z[0];
+              a8[4 * g2 + 2 * h2 + 1] = z[1];
+              m8[4 * g2 + 2 * h2] = sg[0];
+              m8[4 * g2 + 2 * h2 + 1] = sg[1];
+            } else {
+              const v2f a = z * fast_sigmoid2s(z, nsig);
+              a8[4 * g2 + 2 * h2] = a[0];
+              a8[4 * g2 + 2 * h2 + 1] = a[1];
+            }
           }
         } else {
 #pragma unroll
@@ -1056,7 +1080,8 @@ _Pragma("unroll")                                                               
         }
         }
       }
-      split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
+      if constexpr (kMixSplit && kPk && !skip_math) split8_mul<T>(a8, m8, ah_[nb][rg], al_[nb][rg]);
+      else split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
     }
 
   if constexpr ((OPT & 512) != 0) __builtin_amdgcn_s_setprio(0);
@@ -1243,7 +1268,9 @@ _Pragma("unroll")                                                               
 #define FUSED_DBG nullptr
 #define FUSED_START_DELAY 0
 #endif
+#ifndef FUSED_OPT            // (-DFUSED_OPT=...: an A/B build of the production library, build.py variants)
 #define FUSED_OPT 151411     // production options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14, 17 of the kernel)
+#endif
 #define FUSED_OPT_R2 3955    // round 2's production set (register gathers): what the gather / neighbour-sum ablation masks are written for
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
@@ -1304,6 +1331,7 @@ hipError_t launch_fused_opt(A... args) {
     case 20339: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 20339>(args...);  // (A/B: round 3's production: no neighbour-sum fast path)
     case 150899: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 150899>(args...);  // (A/B: production without the raised issue priority)
     case 85875: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 85875>(args...);  // (A/B: full-line gathers through staging registers)
+    case 413555: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 413555>(args...);  // (A/B: production + planes straight from the factors, bit 18)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
   }
 #endif
