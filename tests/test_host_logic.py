@@ -606,3 +606,23 @@ def test_mcts_k_zero_selects_the_smallest_positive_value():
     adj = adj + adj.T
     adj = adj / adj.sum(axis=1, keepdims=True)
     assert np.array_equal(rows, adj)
+
+
+def test_bench_profile_lookups_are_keyed_by_the_run():
+    """bench.py's roofline extras come from committed profiles keyed by the exact run (workload : edges : variant): a run that
+    was never profiled reports None - never another workload's counters - and the power-limited matrix rate is only quoted
+    for the precision it was measured with."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.pmc_traffic_bytes("edge_layer_fused_kernel<FFp16>", "tsp1000", 800000, "fused-fp16x3")
+    assert t is not None and t["bytes_per_launch"] > 1.5e9 and "levels" in t
+    assert bench.pmc_traffic_bytes("edge_layer_fused_kernel<FFp16>", "tsp1000", 800001, "fused-fp16x3") is None
+    assert bench.pmc_pipe_busy("tsp1000", 800001, "fused-fp16x3", 0.72e-3) is None
+    p = bench.pmc_pipe_busy("tsp1000", 800000, "fused-fp16x3", 0.72e-3)
+    assert p is not None and 0.2 < p["value"] < 0.5
+    pl = bench.power_limited_mfma(830.0, "fp16x3")
+    assert pl is not None and 0.4 < pl["frac_of_nominal_peak"] < 0.55 and abs(pl["frac_issued_of_power_limited"] - 830.0 / pl["gemm_only_TFLOPs_issued"]) < 1e-12
+    assert pl["power_cap_W"] == 1400.0 and pl["power_W"] >= 1390.0
+    assert bench.power_limited_mfma(830.0, "bf16x3") is None
