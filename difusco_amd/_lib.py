@@ -7,12 +7,13 @@ from .build import LIB_PATH, PROF_LIB_PATH
 
 FLAG_NO_L0_FOLD, FLAG_NO_TAIL_FOLD, FLAG_CHECK_FINITE = 1, 2, 4      # difusco_step_args.flags
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
 PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3 = 0, 1, 2, 3
 PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6, "fp16x3": PREC_FP16X3}
+AGGREGATIONS = {"sum": 0, "mean": 1, "max": 2}      # DIFUSCO_AGG_* (--aggregation, train.py:52; gnn_encoder.py:170-191)
 
 # indices into difusco_weights_layout() (mirrors the enums of include/difusco_hip.h)
 W_GLOBAL = ["node_embed.weight", "node_embed.bias", "edge_embed.weight", "edge_embed.bias",
@@ -49,6 +50,7 @@ class StepArgs(ctypes.Structure):
         ("row", ctypes.c_void_p),
         ("gn_phase", ctypes.c_int32), ("flags", ctypes.c_int32), ("gn_sums", ctypes.c_void_p),
         ("prepared", ctypes.c_void_p), ("tbias", ctypes.c_void_p),      # optional prepared state (ABI 9)
+        ("aggregation", ctypes.c_int32), ("reserved0", ctypes.c_int32),   # DIFUSCO_AGG_* (ABI 10)
     ]
 
 

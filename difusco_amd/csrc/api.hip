@@ -264,6 +264,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
   if (a->rand_mode == DIFUSCO_RAND_INJECTED && !a->rand) return fail(DIFUSCO_EINVAL, "injected randomness needs rand");
   if (a->rand_mode < 0 || a->rand_mode > 2) return fail(DIFUSCO_EINVAL, "unknown rand_mode %d", a->rand_mode);
   if (a->gn_phase < 0 || a->gn_phase > 2) return fail(DIFUSCO_EINVAL, "gn_phase must be 0, 1 or 2");
+  if (a->aggregation < DIFUSCO_AGG_SUM || a->aggregation > DIFUSCO_AGG_MAX)
+    return fail(DIFUSCO_EINVAL, "unknown aggregation %d (DIFUSCO_AGG_SUM / MEAN / MAX)", a->aggregation);
   if (a->gn_phase != 0 && (a->n_segments != 1 || !a->gn_sums))
     return fail(DIFUSCO_EINVAL, "gn_phase %d needs n_segments == 1 and a gn_sums buffer of 65 doubles", a->gn_phase);
   const bool head_only = a->gn_phase == 2;   // everything up to the statistics was done by the phase-1 call
@@ -313,7 +315,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
   // tiled layout (kernels.h: edge_tiled_offset) from the embedding to the head
   // (per-sample statistic segments - the dense mode of TSP-50 / 100 with parallel_sampling > 1 - run the same fused layers;
   // only the head differs: masked per-segment statistics and a per-row segment look-up, launch_head_tiled)
-  const bool fused = H == 256 && !a->no_fusion && E > 0 &&
+  // (aggregation = max: the fused kernel writes per-tile SUMS of a row's messages; maxima take the unfused sequence)
+  const bool fused = H == 256 && !a->no_fusion && E > 0 && a->aggregation != DIFUSCO_AGG_MAX &&
                      (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
   if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
   // the full-line neighbour-table gathers address node rows by 32-bit byte offsets (4 KB per node): calls with 2^20 nodes or
@@ -462,7 +465,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
       PROF(PROF_GATE, launch_node_finalize((int)N, (int)E, a->rowptr, node4, ws.part, ws.direct, ws.h,
                                            LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
                                            tbias + (size_t)l * H, tsp ? 1 : 0, f16 ? ws.hscale : nullptr, st,
-                                           prep_l ? prep.h0 : nullptr))
+                                           prep_l ? prep.h0 : nullptr, a->aggregation))
       continue;
     }
     PROF(PROF_LINEAR_EDGE, edge_linear(ws.e, LW(l, DIFUSCO_WL_C_W), LW(l, DIFUSCO_WL_C_PLANES), LW(l, DIFUSCO_WL_C_B),
@@ -471,7 +474,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                                LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
                                                LW(l, DIFUSCO_WL_NORM_E_W), LW(l, DIFUSCO_WL_NORM_E_B),
                                                LW(l, DIFUSCO_WL_OUT_LN_W), LW(l, DIFUSCO_WL_OUT_LN_B),
-                                               tbias + (size_t)l * H, tsp ? 1 : 0, st))
+                                               tbias + (size_t)l * H, tsp ? 1 : 0, st, a->aggregation))
     PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, LW(l, DIFUSCO_WL_OUT_W), LW(l, DIFUSCO_WL_OUT_PLANES),
                                        LW(l, DIFUSCO_WL_OUT_B), ws.e, ws.e))
   }

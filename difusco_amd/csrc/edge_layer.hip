@@ -7,7 +7,8 @@ namespace difusco {
 // ------------------------------------------------------------------------------------------------
 // node update after the fused edge pass:  h_i += ReLU(LN_h(Uh_i + sum_j gate*Vh_j)) (+ t, MIS)
 // (gnn_encoder.py:115,123,134,447-448).  One wavefront per node; the neighbour sum is assembled from the
-// per-tile pieces written by edge_layer_fused_kernel, in tile order.
+// per-tile pieces written by edge_layer_fused_kernel, in tile order.  agg_mean (aggregation = "mean",
+// gnn_encoder.py:170-171,184-185): the sum is divided by the number of edges of the row (empty row: 0).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_edges, const int* __restrict__ rowptr,
                                                             const float* __restrict__ node4,
@@ -16,7 +17,8 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
                                                             const float* __restrict__ nh_w,
                                                             const float* __restrict__ nh_b,
                                                             const float* __restrict__ tbias, int time_on_edge,
-                                                            float* __restrict__ row_scale, const float* h_in) {
+                                                            float* __restrict__ row_scale, const float* h_in,
+                                                            int agg_mean) {
   constexpr int H = 256;
   const int lane = threadIdx.x & 63;
   const int f = lane * 4;
@@ -35,6 +37,11 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
       else if (b > last) src = part + ((long long)t * 2 + 1) * H;       // owns the tile's last edge
       else src = direct + (long long)i * H;                              // strictly inside the tile
       agg += *reinterpret_cast<const v4f*>(src + f);
+    }
+    if (agg_mean) {      // (wave uniform) true divisions: the value of sum / count
+      const float cnt = (float)(b - a);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) agg[q] = agg[q] / cnt;
     }
   }
   const v4f uh = *reinterpret_cast<const v4f*>(node4 + (long long)i * 4 * H + f);
@@ -141,10 +148,11 @@ hipError_t launch_edge_layer_fused_l0(int mode, float* e, const float* node4, co
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
                                 const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream,
-                                const float* h_in) {
+                                const float* h_in, int agg_mode) {
   if (n_nodes <= 0) return hipSuccess;
+  if (agg_mode != 0 && agg_mode != 1) return hipErrorInvalidValue;      // (max: the pieces would have to be maxima - unfused path)
   hipLaunchKernelGGL(node_finalize_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, stream, n_nodes, n_edges,
-                     rowptr, node4, part, direct, h, nh_w, nh_b, tbias, time_on_edge, row_scale, h_in ? h_in : h);
+                     rowptr, node4, part, direct, h, nh_w, nh_b, tbias, time_on_edge, row_scale, h_in ? h_in : h, agg_mode);
   return hipGetLastError();
 }
 

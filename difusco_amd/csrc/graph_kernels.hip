@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void table_rows_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // CSR edge gate + neighbour aggregation + the two LayerNorms on the edge row
 //   e'    = Ah[j] + Bh[i] + Ce                         gnn_encoder.py:110
-//   agg_i = sum_j sigmoid(e') * Vh[j]                  :112,:115,:163,:177-191 (aggregation='sum')
+//   agg_i = sum_j sigmoid(e') * Vh[j]                  :112,:115,:163,:177-191 (aggregation='sum'; agg_mode 1 'mean': the sum
+//           divided by the row length, 2 'max': the maximum over the row's edges, 0 for an empty row - :170-173,184-188,
+//           torch_sparse.mean / max = torch_scatter segment_csr semantics)
 //   h_i  += ReLU(LN_h(Uh[i] + agg_i)) (+ tbias, MIS)   :123,:134,:447-448
 //   act   = SiLU(LN_o(ReLU(LN_e(e')) (+ tbias, TSP)))  :131,:135,:445, per_layer_out[l][0:2] :339-342
 // One wavefront owns one centre node i and walks its CSR row (latency of the four dependent wave
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void edge_gate_aggregate_kernel(
     int n_nodes, const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ node4,
     float* ce_act, float* h, const float* __restrict__ nh_w, const float* __restrict__ nh_b,
     const float* __restrict__ ne_w, const float* __restrict__ ne_b, const float* __restrict__ ol_w,
-    const float* __restrict__ ol_b, const float* __restrict__ tbias, int time_on_edge) {
+    const float* __restrict__ ol_b, const float* __restrict__ tbias, int time_on_edge, int agg_mode) {
   constexpr int H = 64 * VEC;
   const int lane = threadIdx.x & 63;
   const int f = lane * VEC;
@@ -200,11 +202,12 @@ __global__ __launch_bounds__(256) void edge_gate_aggregate_kernel(
   const Vec<VEC> g_o = ldv<VEC>(ol_w + f), b_o = ldv<VEC>(ol_b + f);
   const Vec<VEC> tb = ldv<VEC>(tbias + f);
 
+  const int s_begin = rowptr[i], s_end = rowptr[i + 1];
+  const bool agg_max = agg_mode == 2 && s_end > s_begin;      // (wave uniform)
   Vec<VEC> agg;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) agg.v[v] = 0.0f;
+  for (int v = 0; v < VEC; ++v) agg.v[v] = agg_max ? -__builtin_inff() : 0.0f;
 
-  const int s_begin = rowptr[i], s_end = rowptr[i + 1];
   for (int s = s_begin; s < s_end; ++s) {
     const int j = col[s];
     const float* nj = node4 + (long long)j * 4 * H;
@@ -216,7 +219,8 @@ __global__ __launch_bounds__(256) void edge_gate_aggregate_kernel(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       e.v[v] = (ah.v[v] + bh.v[v]) + ce.v[v];
-      agg.v[v] += sigmoidf_(e.v[v]) * vh.v[v];
+      if (agg_max) agg.v[v] = __builtin_fmaxf(agg.v[v], sigmoidf_(e.v[v]) * vh.v[v]);      // (wave uniform)
+      else agg.v[v] += sigmoidf_(e.v[v]) * vh.v[v];
     }
     Vec<VEC> y = wave_layer_norm<VEC>(e, g_e, b_e);
 #pragma unroll
@@ -230,6 +234,11 @@ __global__ __launch_bounds__(256) void edge_gate_aggregate_kernel(
     stv<VEC>(cp, z);
   }
 
+  if (agg_mode == 1 && s_end > s_begin) {
+    const float cnt = (float)(s_end - s_begin);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) agg.v[v] = agg.v[v] / cnt;
+  }
   Vec<VEC> hn;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) hn.v[v] = uh.v[v] + agg.v[v];
@@ -721,12 +730,13 @@ hipError_t launch_table_rows(const float* x, const int* perm, const float* table
 hipError_t launch_edge_gate_aggregate(int H, int n_nodes, const int* rowptr, const int* col, const float* node4,
                                       float* ce_act, float* h, const float* nh_w, const float* nh_b, const float* ne_w,
                                       const float* ne_b, const float* ol_w, const float* ol_b, const float* tbias,
-                                      int time_on_edge, hipStream_t stream) {
+                                      int time_on_edge, hipStream_t stream, int agg_mode) {
   if (n_nodes == 0) return hipSuccess;
+  if (agg_mode < 0 || agg_mode > 2) return hipErrorInvalidValue;
   const unsigned blocks = (unsigned)((n_nodes + 3) / 4);
   DIFUSCO_VEC_DISPATCH(H, hipLaunchKernelGGL((edge_gate_aggregate_kernel<VEC>), dim3(blocks), dim3(256), 0, stream,
                                              n_nodes, rowptr, col, node4, ce_act, h, nh_w, nh_b, ne_w, ne_b, ol_w, ol_b,
-                                             tbias, time_on_edge))
+                                             tbias, time_on_edge, agg_mode))
   return hipGetLastError();
 }
 

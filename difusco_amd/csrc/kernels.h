@@ -103,7 +103,8 @@ extern unsigned long long* g_fused_dbg;
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
                                 const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream,
-                                const float* h_in = nullptr);
+                                const float* h_in = nullptr, int agg_mode = 0);
+// agg_mode (DIFUSCO_AGG_*): 0 sum, 1 mean (sum / row length), 2 max (unfused kernel only) - gnn_encoder.py:170-191
 
 // tbias[i][l][:] = time_layer_l(time_embed(timestep_embedding(t_host[i]))) for n_t diffusion times (HOST array)
 hipError_t launch_time_bias(const float* t_host, int n_t, int H, int n_layers, const float* freqs, const float* w0,
@@ -127,7 +128,7 @@ hipError_t launch_head_tiled(int C, const float* feat, long long rows, int nblk,
 hipError_t launch_edge_gate_aggregate(int H, int n_nodes, const int* rowptr, const int* col, const float* node4,
                                       float* ce_act, float* h, const float* nh_w, const float* nh_b, const float* ne_w,
                                       const float* ne_b, const float* ol_w, const float* ol_b, const float* tbias,
-                                      int time_on_edge, hipStream_t stream);
+                                      int time_on_edge, hipStream_t stream, int agg_mode = 0);
 int gn_blocks_for(long long rows);
 hipError_t launch_head(int H, int C, const float* feat, const int* seg_ptr, int n_segments, long long total_rows,
                        int nblk, double* partial, float* stats, const float* gn_w, const float* gn_b,

@@ -70,7 +70,7 @@ int64_t workspace_bytes(int64_t hidden, int64_t n_layers, int64_t n_nodes, int64
 
 // One reverse-diffusion step on the current stream of `weights`' device.  `post` holds the 5 (categorical) / 5 (gaussian)
 // host-computed posterior constants (include/difusco_hip.h: difusco_step_args.post); `cfg` = {hidden, n_layers,
-// out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}.
+// out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags[, aggregation]}.
 std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
     int diffusion, const at::Tensor& weights, const at::Tensor& rowptr, const at::Tensor& col,
     const c10::optional<at::Tensor>& perm, const c10::optional<at::Tensor>& row, const c10::optional<at::Tensor>& seg_ptr,
@@ -78,7 +78,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
     const c10::optional<at::Tensor>& rand, int64_t seed, int64_t offset, at::Tensor workspace, c10::ArrayRef<int64_t> cfg,
     bool want_pred, bool want_prob, const c10::optional<at::Tensor>& gn_sums, const c10::optional<at::Tensor>& prepared,
     const c10::optional<at::Tensor>& tbias) {
-  TORCH_CHECK(cfg.size() == 9, "cfg = {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}");
+  TORCH_CHECK(cfg.size() == 9 || cfg.size() == 10,
+              "cfg = {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags[, aggregation]}");
   TORCH_CHECK(post.size() <= 8, "post holds at most 8 constants");
   need(weights, at::kFloat, "weights", true);
   need(rowptr, at::kInt, "rowptr", true);
@@ -133,6 +134,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
   a.gn_phase = (int32_t)cfg[7];
   a.flags = (int32_t)cfg[8];
   a.gn_sums = static_cast<double*>(const_cast<void*>(ptr_or_null(gn_sums)));
+  a.aggregation = cfg.size() > 9 ? (int32_t)cfg[9] : DIFUSCO_AGG_SUM;      // (ABI 10; a 9-entry cfg means "sum")
   a.prepared = ptr_or_null(prepared);                       // optional prepared state (include/difusco_hip.h, ABI 9)
   a.tbias = static_cast<const float*>(ptr_or_null(tbias));
   if (a.tbias) {
@@ -151,7 +153,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
 // time-bias rows of a whole schedule.  cfg as in step_impl (only hidden, n_layers, out_channels, precision are read).
 at::Tensor prepare_state(const at::Tensor& weights, const at::Tensor& points, int64_t n_nodes, int64_t n_edges,
                          int64_t n_segments, at::Tensor workspace, c10::ArrayRef<int64_t> cfg) {
-  TORCH_CHECK(cfg.size() == 9, "cfg = {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}");
+  TORCH_CHECK(cfg.size() == 9 || cfg.size() == 10,
+              "cfg = {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags[, aggregation]}");
   need(weights, at::kFloat, "weights", true);
   need(points, at::kFloat, "points", true);
   TORCH_CHECK(points.numel() == 2 * n_nodes, "points must be [n_nodes, 2]");
@@ -181,7 +184,7 @@ at::Tensor prepare_state(const at::Tensor& weights, const at::Tensor& points, in
 }
 
 at::Tensor time_bias_rows(const at::Tensor& weights, c10::ArrayRef<double> times, c10::ArrayRef<int64_t> cfg) {
-  TORCH_CHECK(cfg.size() == 9 && !times.empty(), "cfg (9 entries) and at least one time required");
+  TORCH_CHECK((cfg.size() == 9 || cfg.size() == 10) && !times.empty(), "cfg (9 or 10 entries) and at least one time required");
   need(weights, at::kFloat, "weights", true);
   const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(weights.device());
   std::vector<float> t(times.begin(), times.end());

@@ -54,8 +54,8 @@ def broadcast_weights(state_dict: Optional[dict], device, src: int = 0, group=No
 
 
 def engine_from_broadcast(state_dict: Optional[dict], device, src: int = 0, group=None, precision: str = "fp16x3",
-                          fused: bool = True, flags: int = 0, backend: Optional[str] = None):
+                          fused: bool = True, flags: int = 0, backend: Optional[str] = None, aggregation: str = "sum"):
     from .engine import DenoiseEngine
     (hidden, n_layers, out_channels), blob = broadcast_weights(state_dict, device, src, group)
     return DenoiseEngine(device=device, blob=blob, config=(hidden, n_layers, out_channels), precision=precision, fused=fused,
-                         flags=flags, backend=backend)
+                         flags=flags, backend=backend, aggregation=aggregation)

@@ -29,10 +29,11 @@ def _op_call(fn, *args):
 
 class DenoiseEngine:
     def __init__(self, state_dict=None, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
-                 fused: bool = True, backend: Optional[str] = None, flags: int = 0, config=None):
+                 fused: bool = True, backend: Optional[str] = None, flags: int = 0, config=None, aggregation: str = "sum"):
         """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
         ``blob`` + ``config=(hidden, n_layers, out_channels)``: an already packed blob (e.g. received by RCCL broadcast)
-        instead of a state_dict to pack here."""
+        instead of a state_dict to pack here.  ``aggregation``: the reference's ``--aggregation`` (``train.py:52``,
+        ``gnn_encoder.py:170-191``): "sum" (every published run), "mean" (fused layers too) or "max" (unfused kernels)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.DifuscoHipError("DenoiseEngine needs a GPU device (no CPU fallback exists)")
@@ -54,6 +55,9 @@ class DenoiseEngine:
         if precision not in _lib.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}")
         self.precision = precision
+        if aggregation not in _lib.AGGREGATIONS:
+            raise ValueError(f"aggregation must be one of {sorted(_lib.AGGREGATIONS)}")
+        self.aggregation = aggregation
         self.fused = fused          # fused edge-layer kernel (H == 256, precision bf16x3 / fp16x3)
         self.flags = int(flags)     # difusco_step_args.flags (_lib.FLAG_*): per-call A/B switches of the fused path
         if backend is None:
@@ -96,9 +100,10 @@ class DenoiseEngine:
         return ws
 
     def _cfg(self, task: int = _lib.TASK_TSP, xt_is_binary: bool = False, phase: int = 0):
-        """cfg list of the torch ops: {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags}"""
+        """cfg list of the torch ops: {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags,
+        aggregation}"""
         return [self.hidden, self.n_layers, self.out_channels, task, _lib.PRECISIONS[self.precision], 0 if self.fused else 1,
-                1 if xt_is_binary else 0, phase, self.flags]
+                1 if xt_is_binary else 0, phase, self.flags, _lib.AGGREGATIONS[self.aggregation]]
 
     # ---- prepared state (difusco_step_args.prepared / .tbias) --------------------------------------
     def prepare_times(self, ts) -> None:
@@ -125,7 +130,8 @@ class DenoiseEngine:
         """The step-invariant part of a TSP step for (these weights, this graph, these coordinates) - node embedding,
         layer 0's node linear, the two-row edge-input table (``difusco_prepare``) - as an opaque device buffer to hand to
         ``step(prepared=...)``.  None when the fused path does not apply (the step then computes everything itself)."""
-        if not (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_edges > 0):
+        if not (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_edges > 0
+                and self.aggregation != "max"):
             return None
         pts = points.to(self.device, dtype=torch.float32).contiguous()
         if pts.numel() != 2 * g.n_nodes:
@@ -224,6 +230,7 @@ class DenoiseEngine:
         a.gn_phase, a.gn_sums = 0, None
         a.flags = self.flags
         a.prepared, a.tbias = _ptr(prepared), _ptr(tbias)
+        a.aggregation = _lib.AGGREGATIONS[self.aggregation]
         with torch.cuda.device(dev):
             if gn_reduce is None:
                 _lib.check(_lib.lib().difusco_denoise_step(ctypes.byref(a)))

@@ -55,8 +55,8 @@ class COMetaModel:
         self.diffusion_steps = self.args.diffusion_steps
         self.node_feature_only = node_feature_only
         self.sparse = self.args.sparse_factor > 0 or node_feature_only
-        if self.args.aggregation != "sum":   # gnn_encoder.py:184-188: every published run uses sum
-            raise NotImplementedError("only aggregation='sum' is implemented on the HIP path")
+        if self.args.aggregation not in ("sum", "mean", "max"):      # gnn_encoder.py:170-191 (every published run uses sum)
+            raise ValueError(f"Unknown aggregation {self.args.aggregation}")
         if self.diffusion_type == "gaussian":
             self.diffusion = GaussianDiffusion(T=self.diffusion_steps, schedule=self.diffusion_schedule)
             out_channels = 1
@@ -68,7 +68,10 @@ class COMetaModel:
         if engine is None:
             if state_dict is None:
                 raise ValueError("state_dict (reference GNNEncoder weights) or engine required")
-            engine = DenoiseEngine(state_dict, device=device, precision=precision, fused=fused, backend=backend, flags=flags)
+            engine = DenoiseEngine(state_dict, device=device, precision=precision, fused=fused, backend=backend, flags=flags,
+                                   aggregation=self.args.aggregation)
+        elif engine.aggregation != self.args.aggregation:
+            raise ValueError(f"the engine aggregates by {engine.aggregation}, the model arguments say {self.args.aggregation}")
         if engine.out_channels != out_channels:
             raise ValueError(f"weights have {engine.out_channels} output channels, "
                              f"{self.diffusion_type} diffusion needs {out_channels}")

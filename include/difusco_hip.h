@@ -24,19 +24,21 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 9
+#define DIFUSCO_ABI_VERSION 10
 
 enum {
   DIFUSCO_OK = 0,
   DIFUSCO_EINVAL = -1,      /* bad argument (shape, null pointer, unsupported hidden size ...) */
   DIFUSCO_EWORKSPACE = -2,  /* workspace too small */
   DIFUSCO_EHIP = -3,        /* a HIP runtime call failed */
-  DIFUSCO_EUNSUPPORTED = -4, /* e.g. aggregation other than "sum" (gnn_encoder.py:184-188) */
+  DIFUSCO_EUNSUPPORTED = -4, /* a combination the library has no kernel for */
   DIFUSCO_ENONFINITE = -5    /* DIFUSCO_FLAG_CHECK_FINITE: the step produced inf / nan */
 };
 
 enum { DIFUSCO_TASK_TSP = 0, DIFUSCO_TASK_MIS = 1 };            /* edge features | node features only */
 enum { DIFUSCO_CATEGORICAL = 0, DIFUSCO_GAUSSIAN = 1 };
+/* neighbourhood aggregation of the GNN layers (--aggregation, train.py:52; gnn_encoder.py:170-191): every published run uses sum */
+enum { DIFUSCO_AGG_SUM = 0, DIFUSCO_AGG_MEAN = 1, DIFUSCO_AGG_MAX = 2 };
 enum {
   DIFUSCO_PREC_FP32 = 0,   /* E-row linears on v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fma chain) */
   DIFUSCO_PREC_BF16X3 = 1, /* 2 bf16 planes, 3 products: ~2^-17 relative per product                    */
@@ -193,6 +195,13 @@ typedef struct difusco_step_args {
    * Same kernels, same operands: a step with prepared state is bit-identical to the stateless one (GPU test). */
   const void* prepared;
   const float* tbias;
+  /* ABI 10.  DIFUSCO_AGG_*: h_i = U h_i + Aggr_j(gate_ij * V h_j) over the edges of centre node i (gnn_encoder.py:115,144-191).
+   * SUM: torch_sparse.sum / torch.sum(dim=2).  MEAN: the sum divided by the number of edges of the row (torch_sparse.mean =
+   * segment mean; the dense layer divides by sum(ones) = V).  MAX: the maximum over the row's edges (torch_sparse.max /
+   * torch.max(dim=2)[0]); an empty row aggregates to 0 in all three.  MEAN runs the fused layers (the division happens where the
+   * pieces of a row are added); MAX always takes the unfused kernel sequence (2.5x slower at H = 256). */
+  int32_t aggregation;
+  int32_t reserved0;      /* 0 */
 } difusco_step_args;
 
 enum {

@@ -18,6 +18,9 @@ Parity pin status (see tests/golden/PROVENANCE.md and DESIGN.md):
     ``/root/reference``.  The aggregation semantics are taken from the call site
     ``difusco/models/gnn_encoder.py:177-191``: out[r] = sum of value[k] over edge_index[0][k]==r.
     For the sparse aggregation alone the parity is therefore "unpinned" against torch-sparse.
+  * aggregation = "mean" / "max": the dense branch is pinned against the imported reference
+    (tests/golden/make_golden_agg.py); the sparse branch (torch_sparse.mean / max) is restated in
+    ``segment_aggregate`` and must reproduce the reference's DENSE outputs on the complete graph.
 """
 from __future__ import annotations
 
@@ -167,8 +170,28 @@ def segment_sum(values: torch.Tensor, rows: torch.Tensor, n_rows: int) -> torch.
     return out
 
 
+def segment_aggregate(values: torch.Tensor, rows: torch.Tensor, n_rows: int, aggregation: str = "sum") -> torch.Tensor:
+    """Aggr over the entries of each row, gnn_encoder.py:177-191: torch_sparse.sum / mean / max of
+    SparseTensor(row, col, value) over dim=1.  torch-sparse 0.6.15 (environment.yml:131) reduces over dim 1 with
+    torch_scatter.segment_csr(value, rowptr, reduce=...) (torch_sparse/reduce.py; torch-scatter 2.0.9), whose published
+    semantics are restated here: "mean" = sum / number of entries of the row, "max" = element-wise maximum of the row's
+    entries (values only, like ``torch.max(dim)[0]``); a row without entries yields 0 for every reduction.  The DENSE
+    branch of the same function (:169-175: ``sum / sum(graph)`` with graph = ones, ``torch.max(Vh, dim=2)[0]``) is pure torch
+    and pins these semantics through the reference-generated dense fixtures (tests/golden/tsp_dense_agg_*.npz)."""
+    if aggregation == "sum":
+        return segment_sum(values, rows, n_rows)
+    count = torch.zeros(n_rows, dtype=torch.long).index_add_(0, rows, torch.ones_like(rows))
+    if aggregation == "mean":
+        return segment_sum(values, rows, n_rows) / count.clamp(min=1).to(values.dtype)[:, None]
+    if aggregation == "max":
+        out = torch.full((n_rows, values.shape[-1]), float("-inf"), dtype=values.dtype)
+        out = out.scatter_reduce(0, rows[:, None].expand_as(values), values, reduce="amax", include_self=True)
+        return torch.where((count > 0)[:, None], out, torch.zeros_like(out))
+    raise ValueError(f"unknown aggregation {aggregation}")
+
+
 def sparse_layer(p: Params, l: int, h: torch.Tensor, e: torch.Tensor, ei: torch.Tensor,
-                 tbias: torch.Tensor, time_on_edge: bool, v_on_edges: bool = True):
+                 tbias: torch.Tensor, time_on_edge: bool, v_on_edges: bool = True, aggregation: str = "sum"):
     """GNNLayer.forward(sparse=True, mode='direct') + the epilogue of sparse_encoding.
     gnn_encoder.py:67-142 (layer), :442-449 (epilogue), :339-347 (per_layer_out).
     ei[0] = centre node i (row), ei[1] = neighbour j.  tbias: [1, H] = time_layer(temb)."""
@@ -184,7 +207,7 @@ def sparse_layer(p: Params, l: int, h: torch.Tensor, e: torch.Tensor, ei: torch.
     Ce = _lin(p, L + "C", e)                                  # :104
     e_new = Ah[col] + Bh[row] + Ce                            # :110
     gates = torch.sigmoid(e_new)                              # :112
-    h_new = Uh + segment_sum(gates * Vh, row, h.shape[0])     # :115,163,177-191
+    h_new = Uh + segment_aggregate(gates * Vh, row, h.shape[0], aggregation)   # :115,163,177-191
     h_new = F.relu(_ln(p, L + "norm_h", h_new))               # :123,134
     e_new = F.relu(_ln(p, L + "norm_e", e_new))               # :131,135
     if time_on_edge:
@@ -218,7 +241,7 @@ def group_norm_head(p: Params, feat: torch.Tensor, groups: int = 32) -> torch.Te
 
 def encoder_sparse_edge(p: Params, points: torch.Tensor, xt: torch.Tensor, t: torch.Tensor,
                         ei: torch.Tensor, v_on_edges: bool = True,
-                        return_features: bool = False) -> torch.Tensor:
+                        return_features: bool = False, aggregation: str = "sum") -> torch.Tensor:
     """GNNEncoder.sparse_forward (TSP).  gnn_encoder.py:383-402,416-450.
     points [N,2] f32, xt [E] f32, t [1] f32, ei [2,E] i64 -> logits [E, C]."""
     H = p["node_embed.weight"].shape[0]
@@ -227,13 +250,13 @@ def encoder_sparse_edge(p: Params, points: torch.Tensor, xt: torch.Tensor, t: to
     temb = time_features(p, t, H)                                              # :396
     ei = ei.long()
     for l in range(n_layers_of(p)):
-        h, e = sparse_layer(p, l, h, e, ei, _layer_time_bias(p, l, temb), True, v_on_edges)
+        h, e = sparse_layer(p, l, h, e, ei, _layer_time_bias(p, l, temb), True, v_on_edges, aggregation)
     out = group_norm_head(p, e)
     return (out, h, e) if return_features else out
 
 
 def encoder_sparse_node(p: Params, xt: torch.Tensor, t: torch.Tensor, ei: torch.Tensor,
-                        v_on_edges: bool = True, return_features: bool = False) -> torch.Tensor:
+                        v_on_edges: bool = True, return_features: bool = False, aggregation: str = "sum") -> torch.Tensor:
     """GNNEncoder.sparse_forward_node_feature_only (MIS).  gnn_encoder.py:404-414.
     xt [N] f32, ei [2,E] -> logits [N, C]."""
     H = p["node_embed.weight"].shape[0]
@@ -242,12 +265,12 @@ def encoder_sparse_node(p: Params, xt: torch.Tensor, t: torch.Tensor, ei: torch.
     temb = time_features(p, t, H)
     ei = ei.long()
     for l in range(n_layers_of(p)):
-        h, e = sparse_layer(p, l, h, e, ei, _layer_time_bias(p, l, temb), False, v_on_edges)
+        h, e = sparse_layer(p, l, h, e, ei, _layer_time_bias(p, l, temb), False, v_on_edges, aggregation)
     out = group_norm_head(p, h)
     return (out, h, e) if return_features else out
 
 
-def encoder_dense(p: Params, points: torch.Tensor, xt: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+def encoder_dense(p: Params, points: torch.Tensor, xt: torch.Tensor, t: torch.Tensor, aggregation: str = "sum") -> torch.Tensor:
     """GNNEncoder.dense_forward.  gnn_encoder.py:350-381 and the dense branches of GNNLayer
     (:97,108,119-129,169-175).  points [B,V,2], xt [B,V,V] f32, t [B] -> logits [B,C,V,V].
     Statistics of the head GroupNorm are per sample here (tensor is (B,H,V,V))."""
@@ -265,7 +288,13 @@ def encoder_dense(p: Params, points: torch.Tensor, xt: torch.Tensor, t: torch.Te
         Ce = _lin(p, L + "C", e)
         e_new = Ah[:, None, :, :] + Bh[:, :, None, :] + Ce                     # :108
         gates = torch.sigmoid(e_new)
-        h_new = Uh + torch.sum(gates * Vh, dim=2)                              # :175
+        if aggregation == "mean":                                              # :170-171 (graph = ones, :364: the divisor is V)
+            agg = torch.sum(gates * Vh, dim=2) / torch.sum(torch.ones(B, V, V, dtype=torch.long), dim=2).unsqueeze(-1).type_as(Vh)
+        elif aggregation == "max":                                             # :172-173
+            agg = torch.max(gates * Vh, dim=2)[0]
+        else:
+            agg = torch.sum(gates * Vh, dim=2)                                 # :175
+        h_new = Uh + agg
         h_new = F.relu(_ln(p, L + "norm_h", h_new))
         e_new = F.relu(_ln(p, L + "norm_e", e_new))
         e_new = e_new + _layer_time_bias(p, l, temb)[:, None, None, :]         # :375
@@ -349,50 +378,50 @@ def gaussian_posterior(tables: GaussianTables, t: int, target_t: Optional[int], 
 # ----------------------------------------------------------------------------------------------
 
 def tsp_categorical_denoise_step(p, tables, points, xt, t, edge_index=None, target_t=None,
-                                 uniform=None, generator=None, v_on_edges=True, return_aux=False):
+                                 uniform=None, generator=None, v_on_edges=True, return_aux=False, aggregation="sum"):
     """TSPModel.categorical_denoise_step.  difusco/pl_tsp_model.py:122-138.
     Sparse when edge_index is given (points [N,2], xt [E]); dense otherwise (points [B,V,2],
     xt [B,V,V]).  t / target_t are python ints (the reference passes np arrays of shape (1,))."""
     tf = torch.tensor([float(t)])
     if edge_index is not None:
-        logits = encoder_sparse_edge(p, points, xt.float(), tf, edge_index, v_on_edges)
+        logits = encoder_sparse_edge(p, points, xt.float(), tf, edge_index, v_on_edges, aggregation=aggregation)
         prob0 = logits.reshape((1, points.shape[0], -1, 2)).softmax(dim=-1)    # :135
         nxt, prob = categorical_posterior(tables, t, target_t, prob0, xt, True, uniform, generator)
     else:
-        logits = encoder_dense(p, points, xt.float(), tf)   # one shared timestep, shape (1,)
+        logits = encoder_dense(p, points, xt.float(), tf, aggregation)   # one shared timestep, shape (1,)
         prob0 = logits.permute((0, 2, 3, 1)).contiguous().softmax(dim=-1)      # :133
         nxt, prob = categorical_posterior(tables, t, target_t, prob0, xt, False, uniform, generator)
     return (nxt, logits, prob) if return_aux else nxt
 
 
 def tsp_gaussian_denoise_step(p, tables, points, xt, t, edge_index=None, target_t=None,
-                              inference_trick="ddim", noise=None, v_on_edges=True, return_aux=False):
+                              inference_trick="ddim", noise=None, v_on_edges=True, return_aux=False, aggregation="sum"):
     """TSPModel.gaussian_denoise_step.  pl_tsp_model.py:140-151."""
     tf = torch.tensor([float(t)])
     if edge_index is not None:
-        pred = encoder_sparse_edge(p, points, xt.float(), tf, edge_index, v_on_edges)
+        pred = encoder_sparse_edge(p, points, xt.float(), tf, edge_index, v_on_edges, aggregation=aggregation)
     else:
-        pred = encoder_dense(p, points, xt.float(), tf)
+        pred = encoder_dense(p, points, xt.float(), tf, aggregation)
     pred = pred.squeeze(1)                                                     # :149
     nxt = gaussian_posterior(tables, t, target_t, pred, xt, inference_trick, noise)
     return (nxt, pred) if return_aux else nxt
 
 
 def mis_categorical_denoise_step(p, tables, xt, t, edge_index, target_t=None, uniform=None,
-                                 generator=None, v_on_edges=True, return_aux=False):
+                                 generator=None, v_on_edges=True, return_aux=False, aggregation="sum"):
     """MISModel.categorical_denoise_step.  difusco/pl_mis_model.py:118-128."""
     tf = torch.tensor([float(t)])
-    logits = encoder_sparse_node(p, xt.float(), tf, edge_index, v_on_edges)
+    logits = encoder_sparse_node(p, xt.float(), tf, edge_index, v_on_edges, aggregation=aggregation)
     prob0 = logits.reshape((1, xt.shape[0], -1, 2)).softmax(dim=-1)            # :126
     nxt, prob = categorical_posterior(tables, t, target_t, prob0, xt, True, uniform, generator)
     return (nxt, logits, prob) if return_aux else nxt
 
 
 def mis_gaussian_denoise_step(p, tables, xt, t, edge_index, target_t=None, inference_trick="ddim",
-                              noise=None, v_on_edges=True, return_aux=False):
+                              noise=None, v_on_edges=True, return_aux=False, aggregation="sum"):
     """MISModel.gaussian_denoise_step.  pl_mis_model.py:130-140."""
     tf = torch.tensor([float(t)])
-    pred = encoder_sparse_node(p, xt.float(), tf, edge_index, v_on_edges).squeeze(1)
+    pred = encoder_sparse_node(p, xt.float(), tf, edge_index, v_on_edges, aggregation=aggregation).squeeze(1)
     nxt = gaussian_posterior(tables, t, target_t, pred, xt, inference_trick, noise)
     return (nxt, pred) if return_aux else nxt
 

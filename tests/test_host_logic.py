@@ -384,6 +384,8 @@ def test_step_argument_validation_without_gpu():
     expect_einval(make(n_segments=3), "seg_ptr required")
     expect_einval(make(gn_phase=3), "gn_phase")
     expect_einval(make(gn_phase=1), "gn_sums")
+    expect_einval(make(aggregation=3), "unknown aggregation")
+    expect_einval(make(aggregation=-1), "unknown aggregation")
     with pytest.raises(_lib.DifuscoHipError):
         _lib.check(L.difusco_denoise_step(ctypes.byref(make(hidden=100))))
 

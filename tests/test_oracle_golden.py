@@ -267,3 +267,71 @@ def test_tsp50_dense_full_width_full_length(golden_dir):
             np.testing.assert_allclose(out.numpy().reshape(-1), z["out"][i].reshape(-1), rtol=0, atol=2e-5)
     print(f"TSP-50 dense 50 steps, oracle vs imported reference: logits L_inf {worst_l:.2e}, prob L_inf {worst_p:.2e}")
     assert worst_l < 2e-5 and worst_p < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# --aggregation mean / max (gnn_encoder.py:144-191).  The dense branch is pure torch, so the dense fixtures
+# (tests/golden/make_golden_agg.py) are reference outputs; the sparse branch's torch_sparse.mean / max are restated in
+# O.segment_aggregate and tied to the dense semantics through the complete graph.
+# ------------------------------------------------------------------------------------------------
+AGG_FIXTURES = [("mean", 64, 2, 2), ("mean", 256, 3, 1), ("max", 64, 2, 2), ("max", 256, 3, 1)]
+
+
+@pytest.mark.parametrize("agg,H,L,B", AGG_FIXTURES)
+def test_dense_aggregation_mean_max_vs_reference(agg, H, L, B):
+    from conftest import load_h256_fixture
+    z, cat, gau = load_h256_fixture(f"tsp_dense_agg_{agg}_h{H}_l{L}_b{B}.npz")
+    assert "none executed" in str(z["provenance"]) and str(z["aggregation"]) == agg
+    pts = torch.from_numpy(z["points"])
+    tab, gt = O.CategoricalTables(), O.GaussianTables()
+    _check_cat_steps(z, 3, lambda xt, t, tt, u: O.tsp_categorical_denoise_step(cat, tab, pts, xt, t, None, tt, uniform=u,
+                                                                               return_aux=True, aggregation=agg))
+    _check_gau_steps(z, 2, lambda xt, t, tt: O.tsp_gaussian_denoise_step(gau, gt, pts, xt, t, None, tt, return_aux=True,
+                                                                         aggregation=agg))
+    # the fixture discriminates: the other two aggregations are far outside the tolerance
+    xt0 = torch.from_numpy(z["cat0_xt"]).float()
+    for other in {"sum", "mean", "max"} - {agg}:
+        wrong = O.encoder_dense(cat, pts, xt0, torch.tensor([1000.0]), other)
+        assert np.abs(wrong.numpy() - z["cat0_logits"]).max() > 100 * TOL, other
+
+
+def complete_graph(V):
+    """edge_index of the complete graph with self loops, row-major: the edge list the dense mode stands for"""
+    i = torch.arange(V).repeat_interleave(V)
+    j = torch.arange(V).repeat(V)
+    return torch.stack([i, j])
+
+
+@pytest.mark.parametrize("agg", ["mean", "max"])
+def test_sparse_aggregation_on_the_complete_graph_is_the_reference_dense_output(agg):
+    """One sample: a single GroupNorm statistic segment, so the sparse encoder on the complete graph IS the dense forward
+    (gnn_encoder.py:350-381 vs :383-402) - the restated torch_sparse.mean / max against reference outputs."""
+    from conftest import load_h256_fixture
+    z, cat, gau = load_h256_fixture(f"tsp_dense_agg_{agg}_h256_l3_b1.npz")
+    V = z["points"].shape[1]
+    ei = complete_graph(V)
+    pts = torch.from_numpy(z["points"][0])
+    for i in range(3):
+        t = int(z[f"cat{i}_t"][0])
+        xt = torch.from_numpy(z[f"cat{i}_xt"]).float().reshape(-1)
+        logits = O.encoder_sparse_edge(cat, pts, xt, torch.tensor([float(t)]), ei, aggregation=agg)      # [E, 2]
+        ref = np.transpose(z[f"cat{i}_logits"], (0, 2, 3, 1)).reshape(-1, 2)
+        np.testing.assert_allclose(logits.numpy(), ref, rtol=0, atol=TOL)
+    xg = torch.from_numpy(z["gau0_xt"]).float().reshape(-1)
+    pred = O.encoder_sparse_edge(gau, pts, xg, torch.tensor([1000.0]), ei, aggregation=agg)
+    np.testing.assert_allclose(pred.numpy().reshape(-1), z["gau0_pred"].reshape(-1), rtol=0, atol=TOL)
+
+
+def test_segment_aggregate_semantics():
+    """sum / mean / max over the entries of a row, 0 for a row without entries, any entry order (segment_csr semantics)"""
+    g = torch.Generator().manual_seed(3)
+    rows = torch.tensor([4, 0, 2, 0, 4, 4, 6, 2, 0])
+    v = torch.randn(9, 5, generator=g) - 2.0          # all-negative rows too: the maximum of a non-empty row may be < 0
+    for agg, fn in (("sum", lambda x: x.sum(0)), ("mean", lambda x: x.mean(0)), ("max", lambda x: x.max(0)[0])):
+        out = O.segment_aggregate(v, rows, 8, agg)
+        for r in range(8):
+            sel = v[rows == r]
+            want = fn(sel) if sel.shape[0] else torch.zeros(5)
+            np.testing.assert_allclose(out[r].numpy(), want.numpy(), rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        O.segment_aggregate(v, rows, 8, "median")
