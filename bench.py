@@ -271,10 +271,14 @@ def main():
                     "headline is the median repetition, all of them are listed under `repeats`")
     ap.add_argument("--backend", default=None, choices=["ctypes", "torch"], help="host binding of the C ABI: the PyTorch custom ops "
                     "torch.ops.difusco.* (csrc/torch_ops.cpp; the default) or ctypes (the default with the profiling library)")
+    ap.add_argument("--aggregation", default="sum", choices=["sum", "mean", "max"], help="A/B: the reference's --aggregation "
+                    "(train.py:52); every published run - and the metric - uses sum")
     ap.add_argument("--no-prepare", action="store_true", help="A/B: recompute the step-invariant part of a TSP step (node "
                     "embedding, layer-0 node linear, time-bias rows) in every step instead of once per (graph, schedule)")
     ap.add_argument("--sub-steps", type=int, default=10, help="timed steps of each `workloads` entry (4 warm-up steps; three repetitions)")
     args = ap.parse_args()
+    if args.aggregation != "sum":      # an A/B of the kernels only: the oracle legs and the sub-records are written for the metric (sum)
+        args.cpu_steps, args.no_exact_fp32, args.no_workloads = 0, True, True
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -372,15 +376,15 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         dist.barrier()
         tb0 = time.perf_counter()
         engine = engine_from_broadcast(params, device, src=0, precision=args.precision, fused=not args.no_fusion,
-                                       flags=step_flags, backend=args.backend)
+                                       flags=step_flags, backend=args.backend, aggregation=args.aggregation)
         torch.cuda.synchronize(device)
         broadcast_ms = 1e3 * (time.perf_counter() - tb0)      # rank-0 packing + the RCCL broadcast of the blob
     else:
         engine = DenoiseEngine(params, device=device, precision=args.precision, fused=not args.no_fusion, flags=step_flags,
-                               backend=args.backend)
+                               backend=args.backend, aggregation=args.aggregation)
     margs = dict(diffusion_type=wl["diffusion"], diffusion_schedule="linear", diffusion_steps=1000,
                  inference_diffusion_steps=50, inference_schedule="cosine", sparse_factor=knn if not (mis or dense) else -1,
-                 n_layers=LAYERS, hidden_dim=H, inference_trick="ddim")
+                 n_layers=LAYERS, hidden_dim=H, inference_trick="ddim", aggregation=args.aggregation)
     gn_reduce = gn_allreduce() if (args.gn_stats == "global" and world > 1) else None
     if dry:
         class _PlumbingModel:      # no kernel: hands x_t back, and exercises the statistics all-reduce when asked for
@@ -449,7 +453,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         assert per * args.streams == hi - lo, "--streams must divide the graphs per GPU"
         for k in range(args.streams):
             eng_k = DenoiseEngine(params, device=device, blob=engine.blob, precision=args.precision, fused=not args.no_fusion,
-                                  flags=step_flags)
+                                  flags=step_flags, aggregation=args.aggregation)
             m_k = TSPModel(margs, engine=eng_k, seed=1234 + rank + 100 * k, reorder_nodes=not args.no_node_reorder,
                            prepare=not args.no_prepare)
             p_k, e_k = tsp_batch_gpu(nodes, knn, range(lo + k * per, lo + (k + 1) * per), device)
@@ -565,7 +569,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
                        "fused_opt": args.fused_opt, "debug_set": args.debug_set or None, "streams": args.streams,
                        "binding": ("dry run" if engine is None else "ctypes -> C ABI" if engine.backend == "ctypes" else
                                    "torch.ops.difusco.* custom ops -> C ABI"),
-                       "prepared_state": (not args.no_prepare)},
+                       "prepared_state": (not args.no_prepare), "aggregation": args.aggregation},
         }
         if prof is not None and prof["launches"][0] > 0:
             n_lin = prof["launches"][0]
@@ -650,7 +654,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         if world == 1 and exact_fp32 and args.precision != "fp32":
             # the same workload with every E-row contraction on v_mfma_f32_32x32x2_f32 (exact fp32, no split planes):
             # the number to read when the split-precision arithmetic of the headline is not accepted
-            eng32 = DenoiseEngine(params, device=device, blob=engine.blob, precision="fp32", fused=False)
+            eng32 = DenoiseEngine(params, device=device, blob=engine.blob, precision="fp32", fused=False, aggregation=args.aggregation)
             m32 = (MISModel if mis else TSPModel)(margs, engine=eng32, seed=1234, reorder_nodes=not args.no_node_reorder)
             x32 = one_step(0, xt, m32)
             fence()

@@ -315,13 +315,16 @@ int difusco_denoise_step(const difusco_step_args* a) {
   // tiled layout (kernels.h: edge_tiled_offset) from the embedding to the head
   // (per-sample statistic segments - the dense mode of TSP-50 / 100 with parallel_sampling > 1 - run the same fused layers;
   // only the head differs: masked per-segment statistics and a per-row segment look-up, launch_head_tiled)
-  // (aggregation = max: the fused kernel writes per-tile SUMS of a row's messages; maxima take the unfused sequence)
-  const bool fused = H == 256 && !a->no_fusion && E > 0 && a->aggregation != DIFUSCO_AGG_MAX &&
-                     (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
-  if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
   // the full-line neighbour-table gathers address node rows by 32-bit byte offsets (4 KB per node): calls with 2^20 nodes or
   // more take the register-gather instantiation of the same kernel (64-bit addresses, bit-identical results, ~3 % slower)
   const int reg_gather = N >= (1 << 20) ? 1 : 0;
+  // aggregation = max has fused instantiations of its own (the per-tile pieces are maxima) for the full-line gather form only:
+  // with 2^20 nodes or more it takes the unfused sequence
+  const bool agg_max = a->aggregation == DIFUSCO_AGG_MAX;
+  const bool fused = H == 256 && !a->no_fusion && E > 0 && !(agg_max && reg_gather) &&
+                     (a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3);
+  if (fused && !a->row) return fail(DIFUSCO_EINVAL, "the fused edge-layer kernel needs args->row");
+  const int fused_variant = reg_gather | (agg_max ? 2 : 0);      // (launch_by_mode, edge_layer.hip)
   const int64_t E_pad = (E + 255) / 256 * 256;
   // first layer: when the edge input is a table lookup (categorical TSP: embedding of the bit; MIS: zeros) the fused
   // kernel takes it from the table and the pass that would write e0 to HBM is skipped
@@ -440,7 +443,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                       LW(l, DIFUSCO_WL_NORM_E_B), tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                       LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
                                       table, tsp ? a->xt : nullptr, tsp ? a->perm : nullptr,
-                                      LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st, reg_gather))
+                                      LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st, fused_variant))
     } else if (fused && tail_fold && l == L - 1) {
       PROF(PROF_LINEAR_EDGE,
            launch_edge_layer_fused_tail(a->precision, tsp ? 1 : 2, ws.e, node4, a->row, a->col, (int)E,
@@ -449,7 +452,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                       (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
                                       LW(l, DIFUSCO_WL_NORM_E_B), tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                       LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
-                                      ws.gn_tile, LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st, reg_gather))
+                                      ws.gn_tile, LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, st, fused_variant))
     } else if (fused) {
       PROF(PROF_LINEAR_EDGE,
            launch_edge_layer_fused(a->precision, ws.e, node4, a->row, a->col, (int)E,
@@ -458,7 +461,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                    (long long)H * H, LW(l, DIFUSCO_WL_C_B), LW(l, DIFUSCO_WL_NORM_E_W),
                                    LW(l, DIFUSCO_WL_NORM_E_B), tbias + (size_t)l * H, LW(l, DIFUSCO_WL_OUT_LN_W),
                                    LW(l, DIFUSCO_WL_OUT_LN_B), LW(l, DIFUSCO_WL_OUT_B), tsp ? 1 : 0, ws.part, ws.direct,
-                                   LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, ws.etmax, st, reg_gather))
+                                   LW(l, DIFUSCO_WL_FUSED_SCALES), ws.etmax, ws.etmax, st, fused_variant))
     }
     if (fused && gn_fold && l == L - 1) continue;     // TSP: h is not read after the last layer
     if (fused) {

@@ -7,8 +7,9 @@ namespace difusco {
 // ------------------------------------------------------------------------------------------------
 // node update after the fused edge pass:  h_i += ReLU(LN_h(Uh_i + sum_j gate*Vh_j)) (+ t, MIS)
 // (gnn_encoder.py:115,123,134,447-448).  One wavefront per node; the neighbour sum is assembled from the
-// per-tile pieces written by edge_layer_fused_kernel, in tile order.  agg_mean (aggregation = "mean",
-// gnn_encoder.py:170-171,184-185): the sum is divided by the number of edges of the row (empty row: 0).
+// per-tile pieces written by edge_layer_fused_kernel, in tile order.  agg_mode 1 (aggregation = "mean",
+// gnn_encoder.py:170-171,184-185): the sum is divided by the number of edges of the row (empty row: 0); agg_mode 2 ("max",
+// :172-173,187-188): the pieces are maxima and are combined by maximum (empty row: 0).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_edges, const int* __restrict__ rowptr,
                                                             const float* __restrict__ node4,
@@ -18,14 +19,16 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
                                                             const float* __restrict__ nh_b,
                                                             const float* __restrict__ tbias, int time_on_edge,
                                                             float* __restrict__ row_scale, const float* h_in,
-                                                            int agg_mean) {
+                                                            int agg_mode) {
   constexpr int H = 256;
   const int lane = threadIdx.x & 63;
   const int f = lane * 4;
   const int i = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (i >= n_nodes) return;
   const int a = rowptr[i], b = rowptr[i + 1];
+  const bool agg_mean = agg_mode == 1, agg_max = agg_mode == 2 && b > a;      // (wave uniform)
   v4f agg = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (agg_max) agg = v4f{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   if (b > a) {
     const int t0 = a >> 5, t1 = (b - 1) >> 5;
     for (int t = t0; t <= t1; ++t) {
@@ -36,7 +39,13 @@ __global__ __launch_bounds__(256) void node_finalize_kernel(int n_nodes, int n_e
       if (a <= first) src = part + ((long long)t * 2 + 0) * H;          // owns the tile's first edge
       else if (b > last) src = part + ((long long)t * 2 + 1) * H;       // owns the tile's last edge
       else src = direct + (long long)i * H;                              // strictly inside the tile
-      agg += *reinterpret_cast<const v4f*>(src + f);
+      const v4f piece = *reinterpret_cast<const v4f*>(src + f);
+      if (agg_max) {      // (the pieces are maxima: kinds 8, 9, 11 of the fused kernel)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) agg[q] = __builtin_fmaxf(agg[q], piece[q]);
+      } else {
+        agg += piece;
+      }
     }
     if (agg_mean) {      // (wave uniform) true divisions: the value of sum / count
       const float cnt = (float)(b - a);
@@ -84,10 +93,16 @@ unsigned long long* g_fused_dbg = nullptr;   // device buffer for phase timestam
 
 hipError_t launch_fused_fp16(int kind, FUSED_KIND_PARAMS) { return launch_fused_kind<FFp16>(kind, FUSED_KIND_ARGS); }
 
-// kind + 4: the register-gather instantiation of the same kind (calls with n_nodes >= 2^20)
-static hipError_t launch_by_mode(int mode, int kind, int reg_gather, FUSED_KIND_PARAMS) {
+// variant bit 0: the register-gather instantiation of the same kind (kind + 4; calls with n_nodes >= 2^20);
+// variant bit 1: aggregation = "max" (kind + 8 for the kinds that aggregate; not combined with bit 0)
+static hipError_t launch_by_mode(int mode, int kind, int variant, FUSED_KIND_PARAMS) {
   if (n_edges <= 0) return hipSuccess;
-  if (reg_gather) kind += 4;
+  if (variant & 2) {
+    if (variant & 1) return hipErrorInvalidValue;
+    if (kind != 2) kind += 8;
+  } else if (variant & 1) {
+    kind += 4;
+  }
   if (mode == 1) return launch_fused_bf16(kind, FUSED_KIND_ARGS);     // DIFUSCO_PREC_BF16X3
   if (mode == 3) return launch_fused_fp16(kind, FUSED_KIND_ARGS);     // DIFUSCO_PREC_FP16X3
   return hipErrorInvalidValue;
@@ -150,7 +165,7 @@ hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, con
                                 const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream,
                                 const float* h_in, int agg_mode) {
   if (n_nodes <= 0) return hipSuccess;
-  if (agg_mode != 0 && agg_mode != 1) return hipErrorInvalidValue;      // (max: the pieces would have to be maxima - unfused path)
+  if (agg_mode < 0 || agg_mode > 2) return hipErrorInvalidValue;
   hipLaunchKernelGGL(node_finalize_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, stream, n_nodes, n_edges,
                      rowptr, node4, part, direct, h, nh_w, nh_b, tbias, time_on_edge, row_scale, h_in ? h_in : h, agg_mode);
   return hipGetLastError();

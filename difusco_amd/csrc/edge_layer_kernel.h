@@ -537,6 +537,12 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   constexpr bool kPk = (OPT & 2048) != 0;
   // OPT bit 17: fast path of the neighbour sum for tiles that hold ONE centre node (see FUSED_AGG_ROUND); bit-identical
   constexpr bool kAggFast = (OPT & 131072) != 0;
+  // OPT bit 19 (a SEMANTIC switch, its own instantiations: kinds 8, 9, 11 of launch_fused_kind): aggregation = "max"
+  // (gnn_encoder.py:172-173,187-188) - the per-segment pieces part / direct hold the element-wise MAXIMUM of the gated messages
+  // instead of their sum (node_finalize_kernel then combines the pieces of a node by maximum); the pad lanes of a launch's last
+  // tile contribute -inf instead of 0.  Everything else of the layer is unchanged.
+  constexpr bool kAggMax = (OPT & 524288) != 0;
+  const float agg_neutral = kAggMax ? -__builtin_inff() : 0.0f;
   static_assert(!kPk || kPart, "OPT bit 11 needs bit 6");
   float s1 = 0.0f, s1p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   v2f s1k[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
         const int f = 64 * (rnd) + lane;                                                                                       \
         /* two halves of 16 rows: 32 values in flight at once is the register peak of the kernel (128 accumulators + the */  \
         /* gather buffers are live here) and made the compiler spill accumulators */                                         \
-        float accv = 0.0f;                                                                                                   \
+        float accv = agg_neutral;                                                                                            \
         if (kAggFast && bnd == 0) {                                                                                          \
           /* (wave uniform) ONE centre node in the whole tile - 68 % of the tiles at K = 100: plain column sums in the */    \
           /* same order, without the per-row boundary tests (5 scalar instructions + a taken branch per row) */              \
@@ -585,7 +591,7 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                         \
             for (int k = 0; k < 16; ++k) v[k] = scr[(16 * half + k) * SCR_STRIDE + lane];                                    \
 _Pragma("unroll")                                                                                                         \
-            for (int kk = 0; kk < 16; ++kk) accv += v[kk];                                                                   \
+            for (int kk = 0; kk < 16; ++kk) { if constexpr (kAggMax) accv = __builtin_fmaxf(accv, v[kk]); else accv += v[kk]; } \
             __builtin_amdgcn_sched_barrier(0);                                                                               \
           }                                                                                                                  \
           part0[f] = accv;                                                                                                   \
@@ -602,9 +608,9 @@ _Pragma("unroll")                                                               
               const int node = __builtin_amdgcn_readlane(i_node, k - 1);                                                     \
               float* dst = (k == first_end) ? part0 : direct + (long long)node * H;                                          \
               dst[f] = accv;                                                                                                 \
-              accv = 0.0f;                                                                                                   \
+              accv = agg_neutral;                                                                                            \
             }                                                                                                                \
-            accv += v[kk];                                                                                                   \
+            if constexpr (kAggMax) accv = __builtin_fmaxf(accv, v[kk]); else accv += v[kk];                                  \
           }                                                                                                                  \
           __builtin_amdgcn_sched_barrier(0);                                                                                 \
         }                                                                                                                    \
@@ -638,6 +644,7 @@ _Pragma("unroll")                                                               
   // (ds_write_b128), then read back as before.  No LDS-DMA issue cost, no manual waits (the compiler tracks the staging registers;
   // LDS operations of one wave execute in order), the next block's loads are in flight one whole block ahead.
   constexpr bool kFL3 = kFL && (OPT & 65536) != 0;
+  static_assert(!kAggMax || (kFL && !kFL3), "OPT bit 19 (max aggregation) is written for the production gather path");
   if constexpr (kFL3) {
     const int rsel = lane >> 3, cc = lane & 7;
     auto swz = [](int r) { return ((r >> 1) & 3) | (((r >> 4) & 1) << 2); };
@@ -853,8 +860,8 @@ _Pragma("unroll")                                                               
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
               const v2f sg = sg_q[g][h2] * DIFUSCO_PAIR(vh_q[g], 2 * h2);
-              m[2 * h2] = valid ? sg[0] : 0.0f;
-              m[2 * h2 + 1] = valid ? sg[1] : 0.0f;
+              m[2 * h2] = valid ? sg[0] : agg_neutral;
+              m[2 * h2 + 1] = valid ? sg[1] : agg_neutral;
             }
             *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
           }
@@ -1339,7 +1346,8 @@ hipError_t launch_fused_opt(A... args) {
 
 // one entry point per element type / purpose, each defined in its own translation unit.
 // kind: 0 middle layer, 1 first layer from the 2-row table (L0), 2 last layer of a TSP step (GNP, TAIL 1),
-//       3 last layer of a MIS step (TAIL 2);  + 4: the register-gather instantiation (n_nodes >= 2^20)
+//       3 last layer of a MIS step (TAIL 2);  + 4: the register-gather instantiation (n_nodes >= 2^20);
+//       + 8 (kinds 0, 1, 3): aggregation = "max"
 #define FUSED_KIND_PARAMS                                                                                              \
   float *e, const float *node4, const int *row, const int *col, int n_edges, const unsigned short *c_planes,          \
       const unsigned short *o_planes, long long plane_stride, const float *b_c, const float *g_e, const float *b_e,   \
@@ -1367,6 +1375,10 @@ hipError_t launch_fused_kind(int kind, FUSED_KIND_PARAMS) {
     case 5: return launch_fused_t<T, 0, FUSED_NW, true, false, 0, FUSED_OPT_R2>(FUSED_KIND_ARGS);
     case 6: return launch_fused_t<T, 0, FUSED_NW, false, true, 1, FUSED_OPT_R2>(FUSED_KIND_ARGS);
     case 7: return launch_fused_t<T, 0, FUSED_NW, false, false, 2, FUSED_OPT_R2>(FUSED_KIND_ARGS);
+    // aggregation = "max" (OPT bit 19); the last layer of a TSP step has no neighbour aggregation: kind 2 serves it
+    case 8: return launch_fused_t<T, 0, FUSED_NW, false, false, 0, FUSED_OPT | 524288>(FUSED_KIND_ARGS);
+    case 9: return launch_fused_t<T, 0, FUSED_NW, true, false, 0, FUSED_OPT | 524288>(FUSED_KIND_ARGS);
+    case 11: return launch_fused_t<T, 0, FUSED_NW, false, false, 2, FUSED_OPT | 524288>(FUSED_KIND_ARGS);
     default: return hipErrorInvalidValue;
   }
 }

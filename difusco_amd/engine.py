@@ -33,7 +33,7 @@ class DenoiseEngine:
         """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
         ``blob`` + ``config=(hidden, n_layers, out_channels)``: an already packed blob (e.g. received by RCCL broadcast)
         instead of a state_dict to pack here.  ``aggregation``: the reference's ``--aggregation`` (``train.py:52``,
-        ``gnn_encoder.py:170-191``): "sum" (every published run), "mean" (fused layers too) or "max" (unfused kernels)."""
+        ``gnn_encoder.py:170-191``): "sum" (every published run), "mean" or "max"."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.DifuscoHipError("DenoiseEngine needs a GPU device (no CPU fallback exists)")
@@ -130,8 +130,7 @@ class DenoiseEngine:
         """The step-invariant part of a TSP step for (these weights, this graph, these coordinates) - node embedding,
         layer 0's node linear, the two-row edge-input table (``difusco_prepare``) - as an opaque device buffer to hand to
         ``step(prepared=...)``.  None when the fused path does not apply (the step then computes everything itself)."""
-        if not (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_edges > 0
-                and self.aggregation != "max"):
+        if not (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_edges > 0):
             return None
         pts = points.to(self.device, dtype=torch.float32).contiguous()
         if pts.numel() != 2 * g.n_nodes:

@@ -199,7 +199,8 @@ typedef struct difusco_step_args {
    * SUM: torch_sparse.sum / torch.sum(dim=2).  MEAN: the sum divided by the number of edges of the row (torch_sparse.mean =
    * segment mean; the dense layer divides by sum(ones) = V).  MAX: the maximum over the row's edges (torch_sparse.max /
    * torch.max(dim=2)[0]); an empty row aggregates to 0 in all three.  MEAN runs the fused layers (the division happens where the
-   * pieces of a row are added); MAX always takes the unfused kernel sequence (2.5x slower at H = 256). */
+   * pieces of a row are added); MAX has fused instantiations of its own (the per-tile pieces of a row are maxima); only a MAX call
+   * with n_nodes >= 2^20 takes the unfused kernel sequence. */
   int32_t aggregation;
   int32_t reserved0;      /* 0 */
 } difusco_step_args;

@@ -2,10 +2,11 @@
 HIP path (``-m gpu``; ABI 10: ``difusco_step_args.aggregation``).
 
 * the reference-generated dense fixtures (``tests/golden/make_golden_agg.py``: pure reference arithmetic) through
-  ``TSPModel`` at H = 64 (general kernels, two samples = two statistic segments) and at H = 256 with one sample (mean: the
-  FUSED layers + ``node_finalize``; max: the unfused sequence, chosen by the library);
-* sparse k-NN TSP batches and an Erdos-Renyi MIS graph against the oracle's restated ``torch_sparse.mean / max``, fused and
-  unfused, both bindings, a node without edges included;
+  ``TSPModel`` at H = 64 (general kernels, two samples = two statistic segments) and at H = 256 with one sample (the FUSED
+  layers + ``node_finalize``: mean divides the assembled row sum, max has instantiations whose per-tile pieces are maxima);
+* sparse k-NN TSP batches (edge counts that are and are not multiples of the 32-edge tile; rows longer than a tile) and an
+  Erdos-Renyi MIS graph against the oracle's restated ``torch_sparse.mean / max``, fused and unfused, both bindings, a node
+  without edges included;
 * ``sum`` is untouched: the default engine and an explicit ``aggregation="sum"`` are bit-identical.
 
 Tolerance: network outputs 1e-4 absolute (north_star), observed values printed."""
@@ -71,7 +72,7 @@ def test_golden_dense_mean_max_vs_the_imported_reference(dev, agg, H, L, B, fuse
 @pytest.mark.parametrize("backend", ["ctypes", "torch"])
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("agg", ["mean", "max"])
-@pytest.mark.parametrize("H,Lyr,N,K,G", [(256, 4, 120, 10, 2), (128, 2, 33, 5, 3)])
+@pytest.mark.parametrize("H,Lyr,N,K,G", [(256, 4, 120, 10, 2), (256, 3, 101, 7, 3), (256, 2, 300, 40, 1), (128, 2, 33, 5, 3)])
 def test_sparse_tsp_mean_max_vs_oracle(dev, H, Lyr, N, K, G, agg, fused, backend):
     from difusco_amd import TSPModel
     p = O.init_params(H, Lyr, 2, seed=H + N)
