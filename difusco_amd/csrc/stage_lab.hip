@@ -380,6 +380,154 @@ hipError_t launch(const float* e, const unsigned short* planes, float* out, int 
   return hipGetLastError();
 }
 
+
+// ---- the same GEMM on the 16x16x32 MFMA shape -----------------------------------------------------------------------
+// v_mfma_f32_16x16x32_f16 has the rate of v_mfma_f32_32x32x16_f16 (16 against 32 cycles for half the multiply-adds) but moves
+// fewer accumulator registers per multiply-add: C in + D out are 4 + 4 registers for 8,192 multiply-adds per lane group against
+// 16 + 16 for 16,384 - half - while the A / B operand registers per multiply-add double; LDS traffic is the same (an A fragment is
+// 512 weights in both shapes).  On a chip that runs this GEMM on its power cap (profiles/r04/lab_power_randn_vs_zeros.txt) the
+// question is what the total is worth.  Geometry and synchronisation = the production scheme (32 edges per wave, 4 waves, two
+// workgroups per CU, double-buffered 16 KiB stages, vmcnt + __syncthreads()).  A stage holds 128 weight rows x 32 k (two k slabs
+// of the production plane layout), i.e. stage t = (k block t / 2, row half t % 2); a wave owns 16 feature tiles x 2 edge halves of
+// 16 x 16 accumulators (128 registers, as before).  Operand k order inside an instruction: lane group q = 2 slab + half holds the
+// eight k of that half of that slab, A and B alike.  Results are real (checked against float64 by the bench script).
+template <int MINB>
+__global__ __launch_bounds__(256, MINB) void stage_lab16_kernel(const float* __restrict__ e,
+                                                                const unsigned short* __restrict__ c_planes, long long plane_stride,
+                                                                float* __restrict__ out, float inv_c, int do_store) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  typedef FFp16 T;
+  constexpr int WAVES = 4, PP = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned short* wbuf = reinterpret_cast<unsigned short*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  const int tile = bid * WAVES + wave;
+  const int c16 = lane & 15, q4 = lane >> 4, sl = q4 >> 1, hq = q4 & 1;
+
+  // weight stage requests: piece p = PP wave + i of a plane = (slab p / 4, rows 32 (p % 4) .. + 31 of the row half); lane L fills
+  // LDS slot (row L / 2, half slot L % 2) with the half (L % 2) ^ (row / 8 % 2) of that row (the production swizzle)
+  const __amdgpu_buffer_rsrc_t rs_c =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(c_planes), 0, 0x7fffffff, 0x00020000);
+  const int plane_bytes = (int)plane_stride * 2;
+  unsigned dvoff[PP];
+#pragma unroll
+  for (int i = 0; i < PP; ++i) {
+    const int p = PP * wave + i, half = (lane & 1) ^ ((lane >> 4) & 1);
+    dvoff[i] = ((p >> 2) * 4096 + (32 * (p & 3) + (lane >> 1)) * 16 + half * 8) * 2;      // bytes; + (2 kb) slabs + row half
+  }
+#define LAB16_DMA_STAGE(t)                                                                                                 \
+  {                                                                                                                        \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) _Pragma("unroll") for (int i = 0; i < PP; ++i)                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                                          \
+            rs_c, (__attribute__((address_space(3))) void*)(wbuf + ((t)&1) * BUF + pl * PLANE + (PP * wave + i) * 512),    \
+            16, dvoff[i], (((t) >> 1) * 2 * 4096 + ((t)&1) * 128 * 16) * 2 + pl * plane_bytes, 0, 0);                      \
+  }
+  // e stream: per k block and edge half two float4 per lane (tiled layout: slab 2 kb + sl, i, lane slot = edge + 32 half)
+  const __amdgpu_buffer_rsrc_t rs_e =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e) + (long long)tile * (32 * H), 0, 32 * H * 4, 0x00020000);
+  const int e_voff = (sl * 512 + (c16 + 32 * hq) * 4) * 4;      // bytes; + eh * 16 lanes * 16 B, + kb * 2 slabs, + i * 1 KiB
+  v4f er[2][2][2];
+#define LAB16_E_LOAD(kb)                                                                                                   \
+  {                                                                                                                        \
+    _Pragma("unroll") for (int eh = 0; eh < 2; ++eh) _Pragma("unroll") for (int i = 0; i < 2; ++i)                         \
+        er[(kb)&1][eh][i] = __builtin_bit_cast(                                                                            \
+            v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_e, e_voff + eh * 256, (kb)*4096 + i * 1024, 0));                 \
+  }
+  LAB16_E_LOAD(0)
+  LAB16_E_LOAD(1)
+  LAB16_DMA_STAGE(0)
+
+  v4f acc[16][2];
+#pragma unroll
+  for (int ft = 0; ft < 16; ++ft)
+#pragma unroll
+    for (int eh = 0; eh < 2; ++eh) acc[ft][eh] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  // A fragment of feature tile ft8 of the stage: row 16 ft8 + c16, slab sl, half hq (swizzled)
+  const int a_off = sl * 2048 + c16 * 16 + ((hq ^ ((c16 >> 3) & 1)) << 3);
+  wait_vmcnt<0>();
+  __syncthreads();
+
+  h8 xh[2], xl[2];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    const int kb = t >> 1, rh = t & 1;
+    if (rh == 0) {      // B operands of k block kb, both edge halves
+#pragma unroll
+      for (int eh = 0; eh < 2; ++eh) {
+        const v4f c0 = er[kb & 1][eh][0], c1 = er[kb & 1][eh][1];
+        const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        split8<T>(xs, xh[eh], xl[eh]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < NS) LAB16_DMA_STAGE(t + 1)
+    if (rh == 0 && kb + 2 < 8) LAB16_E_LOAD(kb + 2)
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
+    h8 fh[2], fl[2];
+    fh[0] = *reinterpret_cast<const h8*>(wb);
+    fl[0] = *reinterpret_cast<const h8*>(wb + PLANE);
+#pragma unroll
+    for (int f8 = 0; f8 < 8; ++f8) {
+      if (f8 + 1 < 8) {
+        fh[(f8 + 1) & 1] = *reinterpret_cast<const h8*>(wb + (f8 + 1) * 256);
+        fl[(f8 + 1) & 1] = *reinterpret_cast<const h8*>(wb + PLANE + (f8 + 1) * 256);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int ft = 8 * rh + f8, s0 = f8 & 1;
+      acc[ft][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s0], xh[0], acc[ft][0], 0, 0, 0);
+      acc[ft][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s0], xh[1], acc[ft][1], 0, 0, 0);
+      acc[ft][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s0], xl[0], acc[ft][0], 0, 0, 0);
+      acc[ft][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s0], xl[1], acc[ft][1], 0, 0, 0);
+      acc[ft][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s0], xh[0], acc[ft][0], 0, 0, 0);
+      acc[ft][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s0], xh[1], acc[ft][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t + 1 < NS) {
+      if (rh == 0 && kb + 2 < 8) wait_vmcnt<4>(); else wait_vmcnt<0>();      // the e loads of this stage stay in flight
+      __syncthreads();
+    }
+  }
+#undef LAB16_DMA_STAGE
+#undef LAB16_E_LOAD
+  if (do_store) {      // out tiled like e: feature f = 16 ft + 4 q4 + 0..3 of edge 16 eh + c16
+    float* ot = out + (long long)tile * (32 * H);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft)
+#pragma unroll
+      for (int eh = 0; eh < 2; ++eh) {
+        const v4f v = acc[ft][eh] * inv_c;
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(ot + ft * 512 + (q4 >> 1) * 256 + (16 * eh + c16 + 32 * (q4 & 1)) * 4));
+      }
+  } else {
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" ::"v"(acc[ft][0]), "v"(acc[ft][1]));
+#endif
+    }
+  }
+}
+
+template <int MINB>
+hipError_t launch16(const float* e, const unsigned short* planes, float* out, int n_edges, float inv_c, int do_store, int lds_pad,
+                    hipStream_t st) {
+  static std::atomic<unsigned long long> attr_devices{0};
+  hipError_t er = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&stage_lab16_kernel<MINB>), 160 * 1024);
+  if (er != hipSuccess) return er;
+  if (n_edges % 128 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((stage_lab16_kernel<MINB>), dim3((unsigned)(n_edges / 128)), dim3(256), 2 * BUF * 2 + lds_pad, st, e, planes,
+                     (long long)H * H, out, inv_c, do_store);
+  return hipGetLastError();
+}
+
 }  // namespace LAB_NS
 }  // namespace difusco
 
@@ -461,6 +609,9 @@ int LAB_ENTRY(int variant, const float* e, const void* planes, float* out, int n
     case 2142020: er = launch<32, 4, 2, 0, 2, 0, 1, 1, 2>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
     case 2143120: er = launch<32, 4, 3, 1, 2, 0, 1, 2, 2>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
     case 3142020: er = launch<32, 4, 2, 0, 2, 0, 1, 1, 1>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
+    // the 16x16x32 MFMA shape in the production scheme (two workgroups per CU | one)
+    case 16142020: er = launch16<2>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
+    case 16142021: er = launch16<1>(e, pl, out, n_edges, inv_c, do_store, lds_pad, st); break;
     default: return difusco::set_error(DIFUSCO_EINVAL, "unknown lab variant %d", variant);
   }
 #undef LAB_CASE

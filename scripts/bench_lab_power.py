@@ -24,7 +24,8 @@ os.environ["DIFUSCO_PROFILING_LIB"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from difusco_amd import _lib, graph, weights  # noqa: E402
 
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 142020
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [142020]      # several: randn only, alternating
+variant = variants[0]
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 800_000
 H = 256
 dev = torch.device("cuda:0")
@@ -48,6 +49,7 @@ def smi():
 
 
 def case(name, x, seconds=5.0):
+    global variant
     e_t = graph.to_tiled(x.to(dev))
     out = torch.zeros_like(e_t)
     run = lambda: _lib.check(L.difusco_lab_gemm1_nopk(variant, P(e_t), P(fp16_planes), P(out), E, inv_c, 0, 0, st))
@@ -80,14 +82,22 @@ def case(name, x, seconds=5.0):
            "power_W": [s[0] for s in body], "sclk_MHz": [s[1] for s in body]}
     pw = sorted(rec["power_W"])
     ck = sorted(c for c in rec["sclk_MHz"] if c)
-    print(f"{name:6s}: {ms:.4f} ms / launch ({rec['mfma_TF_issued']:.0f} TF issued = {rec['mfma_TF_issued'] / 2500:.3f} of 2.5 PF), "
+    print(f"{name:14s}: {ms:.4f} ms / launch ({rec['mfma_TF_issued']:.0f} TF issued = {rec['mfma_TF_issued'] / 2500:.3f} of 2.5 PF), "
           f"socket power median {pw[len(pw) // 2] if pw else None} W, sclk median {ck[len(ck) // 2] if ck else None} MHz  ({n} launches)", flush=True)
     return rec
 
 
 recs = [case("idle-check", torch.zeros(E, H), seconds=0.5)]      # (warms the driver path; not reported)
-recs = [case("randn", torch.randn(E, H, generator=gen)), case("zeros", torch.zeros(E, H)),
-        case("randn", torch.randn(E, H, generator=gen)), case("zeros", torch.zeros(E, H))]
+if len(variants) == 1:
+    recs = [case("randn", torch.randn(E, H, generator=gen)), case("zeros", torch.zeros(E, H)),
+            case("randn", torch.randn(E, H, generator=gen)), case("zeros", torch.zeros(E, H))]
+else:      # same data, the variants in turn, three rounds: a same-box comparison in the power-limited steady state
+    x = torch.randn(E, H, generator=gen)
+    recs = []
+    for rnd in range(3):
+        for v in variants:
+            variant = v
+            recs.append(case(f"randn v{v}", x))
 cap = subprocess.run(["rocm-smi", "-M"], capture_output=True, text=True).stdout
 m = re.search(r"Power \(W\): ([0-9.]+)", cap)
-print(json.dumps({"variant": variant, "E": E, "power_cap_W": float(m.group(1)) if m else None, "cases": recs}))
+print(json.dumps({"variants": variants, "E": E, "power_cap_W": float(m.group(1)) if m else None, "cases": recs}))

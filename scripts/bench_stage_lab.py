@@ -5,7 +5,8 @@ Every variant is checked against a float64 product, then timed in interleaved ro
 
     python scripts/bench_stage_lab.py [variant,variant,...] [E]
 
-Variant code = EPW/32 * 100000 + WAVES * 10000 + NBUF * 1000 + SYNC * 100 + RING * 10 + PRIO (see stage_lab.hip).
+Variant code = EPW/32 * 100000 + WAVES * 10000 + NBUF * 1000 + SYNC * 100 + RING * 10 + PRIO (see stage_lab.hip);
+16142020 / 16142021 = the production scheme on the 16x16x32 MFMA shape (two / one workgroup per CU).
 Output: one line per variant + a JSON record (stdout) for profiles/."""
 import ctypes
 import json
@@ -56,7 +57,8 @@ for v in variants:
     run(v, 1)
     torch.cuda.synchronize()
     code = int(v.rstrip("n"))
-    if code >= 1_000_000 and code // 1_000_000 != 2:      # VMIX 1 / 3: the synthetic epilogue rewrites the accumulators (timing only)
+    vmix = code // 1_000_000 if code < 10_000_000 else 0      # (16xxxxxx: the 16x16x32 MFMA shape, real results)
+    if vmix not in (0, 2):      # VMIX 1 / 3: the synthetic epilogue rewrites the accumulators (timing only)
         ok[v] = None
         continue
     got = graph.from_tiled(out, E)[ref_rows.to(dev)].cpu().double()
