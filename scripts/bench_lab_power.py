@@ -94,10 +94,11 @@ if len(variants) == 1:
 else:      # same data, the variants in turn, three rounds: a same-box comparison in the power-limited steady state
     x = torch.randn(E, H, generator=gen)
     recs = []
-    for rnd in range(3):
+    secs = float(sys.argv[3]) if len(sys.argv) > 3 else 5.0
+    for rnd in range(3 if len(variants) <= 3 else 2):
         for v in variants:
             variant = v
-            recs.append(case(f"randn v{v}", x))
+            recs.append(case(f"randn v{v}", x, seconds=secs))
 cap = subprocess.run(["rocm-smi", "-M"], capture_output=True, text=True).stdout
 m = re.search(r"Power \(W\): ([0-9.]+)", cap)
 print(json.dumps({"variants": variants, "E": E, "power_cap_W": float(m.group(1)) if m else None, "cases": recs}))
