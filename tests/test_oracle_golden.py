@@ -335,3 +335,21 @@ def test_segment_aggregate_semantics():
             np.testing.assert_allclose(out[r].numpy(), want.numpy(), rtol=0, atol=1e-6)
     with pytest.raises(ValueError):
         O.segment_aggregate(v, rows, 8, "median")
+
+
+def test_segment_aggregate_against_torch_segment_reduce():
+    """An independent implementation of the same reductions (PyTorch's own ``torch.segment_reduce`` over sorted segments): equal on
+    every non-empty row; the empty-row convention differs by design (torch: 0 / nan / -inf; torch_scatter's segment_csr, which is
+    what torch_sparse calls: 0 for every reduction) and is the one part that rests on the published semantics alone."""
+    g = torch.Generator().manual_seed(0)
+    n_rows = 50
+    lengths = torch.randint(0, 9, (n_rows,), generator=g)
+    rows = torch.repeat_interleave(torch.arange(n_rows), lengths)
+    v = torch.randn(rows.numel(), 7, generator=g)
+    ne = lengths > 0
+    assert bool((~ne).any()) and bool(ne.any())
+    for agg in ("sum", "mean", "max"):
+        ref = torch.segment_reduce(v, agg, lengths=lengths, axis=0, unsafe=False)
+        out = O.segment_aggregate(v, rows, n_rows, agg)
+        np.testing.assert_allclose(out[ne].numpy(), ref[ne].numpy(), rtol=0, atol=1e-6)
+        assert float(out[~ne].abs().max()) == 0.0
