@@ -624,6 +624,10 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
                                     "frac_fp32_mfma_peak": alg_tf / PEAK_FP32_MFMA_TFLOPS,
                                     "hbm_GBs_algorithmic": hbm_gbs, "hbm_frac_of_8TBs": hbm_gbs / PEAK_HBM_GBS,
                                     "other_ms_per_step": 1e3 * dt / steps - avg_s * 1e3 * n_lin / (steps * repeats)})
+            if traffic:      # measured memory-side bytes (PMC pass of this run key) over the live launch time: what the fabric moves,
+                # memory-side cache hits included (no counter separates them from HBM reads)
+                out["roofline"]["fabric_GBs_measured"] = traffic["bytes_per_launch"] / avg_s / 1e9
+                out["roofline"]["fabric_frac_of_8TBs"] = traffic["bytes_per_launch"] / avg_s / 1e9 / PEAK_HBM_GBS
             n_g = max(prof["launches"][2], 1)
             g_s = prof["ms"][2] / n_g * 1e-3
             if fused:
