@@ -94,7 +94,7 @@ def test_bench_py_multi_rank_plumbing_dry_run(gn_stats):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BENCH_PLUMBING_DRY_RUN="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, BENCH_PLUMBING_DRY_RUN="1", MASTER_ADDR="127.0.0.1", BENCH_FULL_JSON=os.devnull)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--nodes", "40", "--knn", "6", "--graphs-per-gpu", "3", "--gn-stats", gn_stats]
@@ -102,7 +102,10 @@ def test_bench_py_multi_rank_plumbing_dry_run(gn_stats):
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout
+    # the stdout line is the COMPACT record (a 20 KB line was not parsed by the driver): the last line, < 4 KB
+    assert res.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096
     out = json.loads(lines[0])
+    assert "full record" in res.stderr      # the full record goes to stderr (and to bench_full.json)
     assert out["dry_run"] is True and out["metric"].startswith("PLUMBING DRY RUN")
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 6 and out["config"]["graphs_per_gpu"] == 3 and out["config"]["gn_stats"] == gn_stats

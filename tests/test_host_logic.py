@@ -628,3 +628,30 @@ def test_bench_profile_lookups_are_keyed_by_the_run():
     assert pl is not None and 0.4 < pl["frac_of_nominal_peak"] < 0.55 and abs(pl["frac_issued_of_power_limited"] - 830.0 / pl["gemm_only_TFLOPs_issued"]) < 1e-12
     assert pl["power_cap_W"] == 1400.0 and pl["power_W"] >= 1390.0
     assert bench.power_limited_mfma(830.0, "bf16x3") is None
+
+
+def test_bench_stdout_line_is_compact():
+    """the driver could not parse a 20.8 KB bench line.  The stdout line is `compact_record(full)`: the contract's
+    fields + roofline + cpu_baseline + one line per workload, < 4 KB, valid JSON - checked on round 4's full 20.8 KB record."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(__file__))
+    spec = importlib.util.spec_from_file_location("bench_module2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(root, "profiles", "r04", "bench_default.json")))
+    assert len(json.dumps(full)) > 20000
+    full["power"] = {"power_W_median": 1351.0, "power_W_max": 1402.0, "sclk_MHz_median": 1893.0, "samples": 41, "J_per_graph_step": 1.61,
+                     "source": "hwmon power1_average + freq1_input, sampled inside the timed loops"}
+    line = json.dumps(bench.compact_record(full, "/x/bench_full.json"), separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    rec = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "workloads", "repeats", "parity_linf", "ranks_seen", "power"):
+        assert key in rec, key
+    assert rec["value"] == full["value"] and rec["ms_per_step"] == full["ms_per_step"]
+    r = rec["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"]["bytes_per_launch"] > 1e9
+    assert set(rec["workloads"]) == {"tsp500", "tsp10000", "mis", "tsp50dense"}
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] >= 1 and rec["cpu_baseline"]["value"] > 0
+    assert rec["full_record"] == "bench_full.json"
