@@ -650,8 +650,12 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
     if not dry:
         torch.cuda.synchronize(device)
         tp0 = time.perf_counter()
-        for mdl in ([model] if groups is None else [gk["model"] for gk in groups]):
-            mdl.prepare_schedule([sched(i)[0] for i in range(50)])
+        if groups is None:
+            model.prepare_schedule([sched(i)[0] for i in range(50)])
+        else:
+            for gk in groups:      # (the rows are cached per HIP stream: prepared on the stream that will step)
+                with torch.cuda.stream(gk["stream"]):
+                    gk["model"].prepare_schedule([sched(i)[0] for i in range(50)])
         torch.cuda.synchronize(device)
         prepare_ms = 1e3 * (time.perf_counter() - tp0)
     for i in range(warmup):

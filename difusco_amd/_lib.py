@@ -7,7 +7,7 @@ from .build import LIB_PATH, PROF_LIB_PATH
 
 FLAG_NO_L0_FOLD, FLAG_NO_TAIL_FOLD, FLAG_CHECK_FINITE = 1, 2, 4      # difusco_step_args.flags
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
@@ -26,7 +26,7 @@ W_LAYER = ["@node4.weight", "@node4.bias", "layers.{l}.C.weight", "layers.{l}.C.
            "per_layer_out.{l}.0.weight", "per_layer_out.{l}.0.bias",
            "per_layer_out.{l}.2.weight", "per_layer_out.{l}.2.bias",
            "@planes:layers.{l}.C.weight", "@planes:per_layer_out.{l}.2.weight", "@planes:@node4.weight",
-           "@fused_scales"]
+           "@fused_scales", "@node4.fused_bias", "@node4.fused_scale"]
 
 
 class StepArgs(ctypes.Structure):

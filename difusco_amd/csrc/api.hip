@@ -86,6 +86,7 @@ Layout make_layout(int H, int L, int C) {
     push((int64_t)5 * H * H / 2 + H); push((int64_t)5 * H * H / 2 + H);  // split planes of C and per_layer_out (+ inverse scales)
     push((int64_t)5 * 4 * H * H / 2 + 4 * H);                             // split planes of the node linear (+ inverse scales)
     push(8);                                                               // operand scales of the fused edge kernel
+    push((int64_t)4 * H); push((int64_t)8 * H);                            // node linear, fused path: bias, column scales (fp16 | bf16 planes)
     if (l == 0) lo.layer_stride = cur - layer0;
   }
   lo.total = cur;
@@ -428,7 +429,10 @@ int difusco_denoise_step(const difusco_step_args* a) {
         sc.row_scale = ws.hscale;
         sc.w_inv = LW(l, DIFUSCO_WL_NODE4_PLANES) + (long long)5 * 4 * H * H / 2;
       }
-      PROF(PROF_LINEAR_NODE, linear_rows_split(ws.h, npl, (long long)4 * H * H, a->precision, LW(l, DIFUSCO_WL_NODE4_B),
+      // fused edge kernel: A | B rows in its log2(e) domain, b_C folded into the A rows (difusco_hip.h, ABI 11 note)
+      if (fused) sc.w_inv = LW(l, DIFUSCO_WL_NODE4_FUSED_S) + (f16 ? 0 : 4 * H);
+      PROF(PROF_LINEAR_NODE, linear_rows_split(ws.h, npl, (long long)4 * H * H, a->precision,
+                                               LW(l, fused ? DIFUSCO_WL_NODE4_FUSED_B : DIFUSCO_WL_NODE4_B),
                                                nullptr, ws.node4, N, H, 4 * H, 4 * H, st, 0, sc))
     } else {
       PROF(PROF_LINEAR_NODE, linear_rows(ws.h, LW(l, DIFUSCO_WL_NODE4_W), LW(l, DIFUSCO_WL_NODE4_B), nullptr, ws.node4,
@@ -577,7 +581,12 @@ int difusco_prepare(const difusco_step_args* a, void* prepared, size_t prepared_
       sc.row_scale = ws.hscale;
       sc.w_inv = LW(0, DIFUSCO_WL_NODE4_PLANES) + (long long)5 * 4 * H * H / 2;
     }
-    HIP_TRY(linear_rows_split(prep.h0, npl, (long long)4 * H * H, a->precision, LW(0, DIFUSCO_WL_NODE4_B), nullptr,
+    // the prepared rows are read by the fused edge kernel only (difusco_denoise_step: use_prep requires the fused path), so they
+    // are produced in its log2(e) domain whenever the precision has a fused path - same vectors as the step's own node linear
+    const bool fused_prec = a->precision == DIFUSCO_PREC_BF16X3 || a->precision == DIFUSCO_PREC_FP16X3;
+    if (fused_prec) sc.w_inv = LW(0, DIFUSCO_WL_NODE4_FUSED_S) + (f16 ? 0 : 4 * H);
+    HIP_TRY(linear_rows_split(prep.h0, npl, (long long)4 * H * H, a->precision,
+                              LW(0, fused_prec ? DIFUSCO_WL_NODE4_FUSED_B : DIFUSCO_WL_NODE4_B), nullptr,
                               prep.node4_0, N, H, 4 * H, 4 * H, st, 0, sc));
   } else {
     HIP_TRY(linear_rows(prep.h0, LW(0, DIFUSCO_WL_NODE4_W), LW(0, DIFUSCO_WL_NODE4_B), nullptr, prep.node4_0, N, H, 4 * H,
@@ -636,7 +645,9 @@ int difusco_edge_gate_aggregate(int hidden, int n_nodes, const int32_t* rowptr, 
 
 size_t difusco_fused_scratch_bytes(int n_nodes, int n_edges) {
   if (n_nodes < 0 || n_edges < 0) return 0;
-  return sizeof(float) * (fused_part_floats(n_edges) + (size_t)n_nodes * 256 + (size_t)(n_edges + 255) / 256 * 8 + 64) + 256;
+  // pieces of the neighbour sum | direct rows | tile maxima | the node rows in the kernel's log2(e) domain (ABI 11)
+  return sizeof(float) * (fused_part_floats(n_edges) + (size_t)n_nodes * 256 + (size_t)(n_edges + 255) / 256 * 8 + 64 + 64 +
+                          (size_t)n_nodes * 1024) + 256;
 }
 
 int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int32_t* rowptr, const int32_t* row,
@@ -658,13 +669,19 @@ int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int3
   float* etmax = direct + (size_t)n_nodes * 256;
   hipStream_t st = (hipStream_t)stream;
   const long long n_tiles_pad = ((long long)n_edges + 255) / 256 * 8;
+  // The caller's node4 is the reference's U h | V h | A h | B h (gnn_encoder.py:94-103).  The kernel reads the A | B rows in its
+  // log2(e) domain with b_C folded into the A rows (difusco_hip.h, ABI 11 note): converted copy in the scratch.  (The step driver
+  // has no such pass: its node linear produces the rows in that form.)
+  float* node4_k = etmax + (n_tiles_pad + 63) / 64 * 64;
+  HIP_TRY(difusco::launch_fuse_node_tables(node4, b_c, n_nodes, node4_k, st));
   if (precision == DIFUSCO_PREC_FP16X3)      // e-stream scale per tile: normally left by the producer of e
     HIP_TRY(difusco::launch_tile_absmax_tiled(e, n_tiles_pad, etmax, st));
-  HIP_TRY(difusco::launch_edge_layer_fused(precision, e, node4, row, col, n_edges,
+  HIP_TRY(difusco::launch_edge_layer_fused(precision, e, node4_k, row, col, n_edges,
                                            reinterpret_cast<const unsigned short*>(planes_c) + off,
                                            reinterpret_cast<const unsigned short*>(planes_o) + off, 256LL * 256, b_c,
                                            norm_e_w, norm_e_b, tbias, out_ln_w, out_ln_b, b_out, time_on_edge, part,
                                            direct, scales, etmax, etmax, st, n_nodes >= (1 << 20) ? 1 : 0));
+  // (node_finalize reads the U rows, which the conversion copies unchanged: either buffer would do)
   HIP_TRY(difusco::launch_node_finalize(n_nodes, n_edges, rowptr, node4, part, direct, h, norm_h_w, norm_h_b, tbias,
                                         time_on_edge, nullptr, st));
   return DIFUSCO_OK;

@@ -160,6 +160,29 @@ hipError_t launch_edge_layer_fused_l0(int mode, float* e, const float* node4, co
   return launch_by_mode(mode, 1, reg_gather, FUSED_KIND_ARGS);
 }
 
+// The reference's node rows -> the fused kernel's log2(e) domain (only the stand-alone layer entry difusco_edge_layer_fused needs
+// this pass: the step driver's node linear writes the rows in that form).  One thread per float4.
+__global__ __launch_bounds__(256) void fuse_node_tables_kernel(const float* __restrict__ node4, const float* __restrict__ b_c,
+                                                               long long n_vec, float* __restrict__ out) {
+  constexpr float kLog2e = 1.4426950408889634f;
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_vec) return;
+  const int c = (int)(v & 255) * 4;      // column inside the 1024-float row
+  v4f x = *reinterpret_cast<const v4f*>(node4 + v * 4);
+  if (c >= 512) {
+    if (c < 768) x += *reinterpret_cast<const v4f*>(b_c + (c - 512));
+    x = x * kLog2e;
+  }
+  *reinterpret_cast<v4f*>(out + v * 4) = x;
+}
+
+hipError_t launch_fuse_node_tables(const float* node4, const float* b_c, int n_nodes, float* out, hipStream_t stream) {
+  if (n_nodes <= 0) return hipSuccess;
+  const long long n_vec = (long long)n_nodes * 256;
+  hipLaunchKernelGGL(fuse_node_tables_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, stream, node4, b_c, n_vec, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
                                 const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream,

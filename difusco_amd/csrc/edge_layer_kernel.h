@@ -49,7 +49,7 @@ namespace difusco {
 namespace fused {
 constexpr int H = 256;
 constexpr int SCR_STRIDE = 68;           // floats per edge row of the aggregation scratch (64 + 4 pad)
-enum { P_BC = 0, P_GE, P_BE, P_T, P_GO, P_BO, P_BOUT, P_TAB0, P_TAB1, P_CE0, P_CE1, P_COUNT };
+enum { P_GE = 0, P_BE, P_T, P_GO, P_BO, P_BOUT, P_TAB0, P_TAB1, P_CE0, P_CE1, P_COUNT };
 // P_TAB*: layer-0 input table rows; P_CE*: C (weight of GEMM 1) applied to those rows
 
 // Workgroup geometry (template parameter NW = 4, the only one kept): a workgroup is 4 tiles of 32 edges, a weight stage
@@ -72,16 +72,16 @@ struct Geo {
   static constexpr int SPQ = 16 / KPS;          // GEMM 2: stages per output quarter (4)
   static constexpr int NSTAGE = NS1 + 4 * SPQ;  // 32
   static constexpr int LDS_W = 2 * BUF * 2;     // bytes, double buffered                               32768
-  static constexpr int LDS_P = P_COUNT * H * 4; // bytes: b_C, g_e, b_e, t, g_o, b_o, b_O, table rows (4) 11264
+  static constexpr int LDS_P = P_COUNT * H * 4; // bytes: g_e, b_e, t, g_o, b_o, b_O, table rows (4)      10240
   static constexpr int LDS_S = WAVES * 32 * SCR_STRIDE * 4;   // bytes                                  34816
   static constexpr int OFF_P = LDS_W;           // [buffers][parameters][scratch]
   static constexpr int OFF_S = LDS_W + LDS_P;
-  static constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;     //                                        78848
+  static constexpr int LDS_TOTAL = LDS_W + LDS_P + LDS_S;     //                                        77824
 };
 constexpr int geo_waves(int) { return 4; }
 }  // namespace fused
 
-template <typename T, int ABL, int NW, bool L0, bool GNP, int TAIL, int OPT>
+template <typename T, int ABL, int NW, bool L0, bool GNP, int TAIL, int OPT, bool NOTB = false>
 __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused_kernel(
     float* e, const float* __restrict__ node4, const int* __restrict__ row, const int* __restrict__ col, int n_edges,
     const unsigned short* __restrict__ c_planes, const unsigned short* __restrict__ o_planes, long long plane_stride,
@@ -302,12 +302,24 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #define FUSED_STAMP(k) \
   if constexpr ((ABL & 16) != 0) stamp[k] = __builtin_amdgcn_s_memtime();
 
-  float inv2 = 1.0f, sa = 1.0f, nsig = -1.4426950408889634f, inv_c = 1.0f;
+  // LOG2E DOMAIN (round 5).  The pre-activation of the gate, e' = A h[j] + B h[i] + C e + b_C, is carried as e' log2(e): the node-row
+  // linear delivers the A / B rows already multiplied by log2(e) with b_C folded into the A rows (weights.py: node4 "fused" bias /
+  // column-scale vectors), and the accumulator of GEMM 1 is brought in by ONE multiply-add with inv1 = log2(e) 2^-kc 2^-kx.  Then
+  //   sigmoid(e')  = 1 / (1 + exp2(-e' log2(e)))                      no multiply in front of v_exp_f32 (the negation is a source modifier),
+  //   LayerNorm_e  is invariant under the positive factor when eps is scaled by its square (kEps1 below),
+  // i.e. 2 vector instructions per value fewer in the gate (the bias add and the sigmoid's pre-multiply) and no b_C reads from LDS.
+  // The activation of GEMM 2 is produced the same way: z' = z log2(e) straight from LayerNorm_o (g_o, b_o are multiplied by log2(e)
+  // when they are written to LDS), a' = z' / ((1 + exp2(-z')) 2^-ka) = SiLU(z) log2(e) 2^ka with the operand scale 2^ka inside the
+  // multiply-add that forms the denominator; the factor 1 / log2(e) is part of inv2 (the accumulator scale of GEMM 2).
+  // scales (T::kScaled) = {log2(e) 2^-kc, 2^-(ko+ka) / log2(e), log2(e), 2^-ka}; unscaled planes (bf16): {log2(e), 1 / log2(e), log2(e), 1}.
+  constexpr float kLog2e = 1.4426950408889634f;
+  constexpr float kEps1 = 1e-5f * kLog2e * kLog2e;      // LayerNorm_e on e' log2(e)
+  float inv2 = 1.0f / kLog2e, gmul = kLog2e, s_den = 1.0f, inv_c = kLog2e;
   if constexpr (T::kScaled) {
     inv_c = scales[0];
     inv2 = scales[1];
-    sa = scales[2];
-    nsig = scales[3];
+    gmul = scales[2];
+    s_den = scales[3];
   }
   // ---- once per workgroup: requests of its first tile, layer parameters -> LDS (thread = feature) ------------------
   if (wt < wt_end) {
@@ -318,18 +330,17 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     if constexpr (!(kLate16 && L0)) { FUSED_DMA_STAGE(FIRST_T) }
   }
   if (tid < H) {
-    prm[P_BC * H + tid] = b_c[tid];
     prm[P_GE * H + tid] = g_e[tid];
     prm[P_BE * H + tid] = b_e[tid];
     prm[P_T * H + tid] = time_on_edge ? tbias[tid] : 0.0f;
-    prm[P_GO * H + tid] = g_o[tid] * sa;      // LN_o output arrives as z 2^ka (exact)
-    prm[P_BO * H + tid] = b_o[tid] * sa;
+    prm[P_GO * H + tid] = g_o[tid] * gmul;      // LN_o output arrives as z log2(e)
+    prm[P_BO * H + tid] = b_o[tid] * gmul;
     prm[P_BOUT * H + tid] = b_out[tid];
     if constexpr (L0) {
       prm[P_TAB0 * H + tid] = l0_table[tid];
       prm[P_TAB1 * H + tid] = l0_table[H + tid];
-      prm[P_CE0 * H + tid] = l0_table[2 * H + tid];
-      prm[P_CE1 * H + tid] = l0_table[3 * H + tid];
+      prm[P_CE0 * H + tid] = l0_table[2 * H + tid] * kLog2e;      // (C e_in, carried in the log2(e) domain like the accumulators)
+      prm[P_CE1 * H + tid] = l0_table[3 * H + tid] * kLog2e;
     }
   }
   const int a_off = wslot(l31, hh);   // entry = 32 nb + l31 : (entry >> 3) & 1 == (l31 >> 3) & 1
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
     if constexpr (kNtSt) __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p));
     else *reinterpret_cast<v4f*>(p) = v;
   };
-  float sx = 1.0f, inv1 = 1.0f;
+  float sx = 1.0f, inv1 = inv_c;      // accumulator of GEMM 1 -> e' log2(e): log2(e) (2^-kc 2^-kx)
   if constexpr (T::kScaled && !L0) {
     float invx;
     sx = pow2_scale_for(tmax_cur, invx);      // (wave uniform: scalar arithmetic)
@@ -413,14 +424,6 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // stage then ends with vmcnt(2) instead of vmcnt(0): the weight pieces have landed (requests complete in order), the
   // e loads stay in flight across the barrier and are waited for at the end of the NEXT stage.
   constexpr bool kDeepE = (OPT & 32) != 0;
-  // OPT bit 18: the 16-bit planes of a PRODUCT straight from its two factors (T::split_pair_mul: four v_fma_mix{lo,hi}_f16 per
-  // pair instead of two multiplies + the six-instruction split) - the scaled e slabs of GEMM 1 (bit-identical) and the
-  // activation z sigmoid(z) of GEMM 2 (the product is no longer rounded to fp32 before the split: last bit of the lo plane).
-  // 256 of the kernel's ~5,100 vector instructions per tile - and measured SLOWER (same box, 3 + 3 interleaved runs, profiles/r04/
-  // exp_mix_split.txt): TSP-1000 0.7598 vs 0.7493 ms per launch, MIS 1.182 vs 1.171, TSP-500 0.402 vs 0.400, TSP-10000 equal.
-  // The count of vector instructions is not what the epilogue costs; the half-register writes chain (mixhi waits for mixlo)
-  // and every group of them draws a wait state.  Not in the production set.
-  constexpr bool kMixSplit = (OPT & 262144) != 0;
   static_assert(!kDeepE || (SPS == 1 && RING == 2), "OPT bit 5 is written for the 16 KiB stages");
 #pragma unroll
   for (int t = 0; t < (L0 ? 0 : NS1); ++t) {
@@ -439,18 +442,12 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
           er[ks % RING][1] = ld_e(((ks + RING) * 512 + 256), kBufRing);
         }
       }
-      if constexpr (kMixSplit && T::kScaled) {      // scale and split in one go (bit-identical planes: the scale is a power of two)
-        const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        const float ms[8] = {sx, sx, sx, sx, sx, sx, sx, sx};
-        split8_mul<T>(xs, ms, xh[sub], xl[sub]);
-      } else {
-        if constexpr (T::kScaled) {
-          c0 = c0 * sx;
-          c1 = c1 * sx;
-        }
-        const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        split8<T>(xs, xh[sub], xl[sub]);
+      if constexpr (T::kScaled) {
+        c0 = c0 * sx;
+        c1 = c1 * sx;
       }
+      const float xs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      split8<T>(xs, xh[sub], xl[sub]);
     }
     if constexpr (kDeepE) {
       __builtin_amdgcn_sched_barrier(0);
@@ -529,12 +526,12 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // Neighbour-table rows: full-line gathers through LDS (OPT bit 14, production) or register gathers one batch (= 2 quads) ahead.
   // OPT bit 6: the four LayerNorm reductions (sum, centred sum of squares, twice) run as FOUR interleaved partial sums per
   // lane instead of one 128-term serial chain each; same terms, different summation order (fp32 rounding only)
-  constexpr bool kPart = (OPT & 64) != 0;
+  static_assert((OPT & 64) != 0, "OPT bit 6 is part of every kept instantiation (the serial-sum form was removed in round 5)");
   // OPT bit 11: the element-wise arithmetic of the gate, the two LayerNorms and the activation is written on register PAIRS
   // (elements 2p, 2p+1 of an accumulator tuple, .xy / .zw of the parameter vectors) so that it maps to v_pk_add / v_pk_mul /
   // v_pk_fma_f32 without the v_mov pairs hipcc's own vectoriser needed for the pairs it chose; element for element the same
   // operations in the same order as the scalar code (requires bit 6: the partial sums are the pairs' running sums)
-  constexpr bool kPk = (OPT & 2048) != 0;
+  static_assert((OPT & 2048) != 0, "OPT bit 11 is part of every kept instantiation (the scalar form was removed in round 5)");
   // OPT bit 17: fast path of the neighbour sum for tiles that hold ONE centre node (see FUSED_AGG_ROUND); bit-identical
   constexpr bool kAggFast = (OPT & 131072) != 0;
   // OPT bit 19 (a SEMANTIC switch, its own instantiations: kinds 8, 9, 11 of launch_fused_kind): aggregation = "max"
@@ -543,8 +540,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // tile contribute -inf instead of 0.  Everything else of the layer is unchanged.
   constexpr bool kAggMax = (OPT & 524288) != 0;
   const float agg_neutral = kAggMax ? -__builtin_inff() : 0.0f;
-  static_assert(!kPk || kPart, "OPT bit 11 needs bit 6");
-  float s1 = 0.0f, s1p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float s1 = 0.0f;
   v2f s1k[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
   // segment structure of the tile: bit k of bnd = edge k starts a new centre node (wave uniform)
   const int i_prev = __shfl_up(i_node, 1, 64);
@@ -553,9 +549,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   float* part0 = part + ((long long)tile * 2 + 0) * H;
   float* part1 = part + ((long long)tile * 2 + 1) * H;
 
-  // OPT bit 13 (experiment): neighbour-table rows gathered TWO batches ahead of their use (three ring slots) instead of one
-  constexpr bool kG2 = (OPT & 8192) != 0;
-  constexpr int GD = kG2 ? 3 : 2;
+  constexpr int GD = 2;      // register gathers (n_nodes >= 2^20 instantiations): one batch ahead of their use, two ring slots
   v4f ga[GD][2][3];
 #define FUSED_GATHER(b, buf)                                                          \
   {                                                                                   \
@@ -628,7 +622,7 @@ _Pragma("unroll")                                                               
   // One buffer, the two tables alternate: A(nb) is read, V(nb) requested, the gate's e' / sigmoid computed, V(nb) read,
   // A(nb + 1) requested, the messages formed.  Every wait is vmcnt(0): stores share the counter on gfx9.
   constexpr bool kFL = (OPT & 16384) != 0;
-  static_assert(!kFL || (kPk && (ablate & 0x3EF) == 0 && !kG2), "OPT bit 14 is written for the production arithmetic");
+  static_assert(!kFL || (ablate & 0x3EF) == 0, "OPT bit 14 is written for the production arithmetic");
   // ABL 1024 / 2048 (profiling library, wrong results): the full-line gather requests are issued but never waited for / not
   // issued at all - what the waits and what the issue of the 64 LDS-DMA pieces cost in the gather phase
   // OPT bit 15 (with bit 14): TWO units - A in the wave's share of buffer 1, V in its share of buffer 0 - so that the next block
@@ -639,96 +633,7 @@ _Pragma("unroll")                                                               
   // request cannot be pending when the count is reached - whatever the neighbour-sum stores (same counter) do.
   constexpr bool kFL2 = kFL && (OPT & 32768) != 0;
   static_assert(!kFL2 || !kPersist, "bits 12 and 15 are not combined");
-  // OPT bit 16 (with bit 14, experiment): the same full-line access pattern, but through REGISTERS - four buffer_load_dwordx4 per
-  // unit land in staging registers (lane L: row 8 p + L / 8, chunk (L % 8) ^ swz(row)) and are written to the unit lane-linearly
-  // (ds_write_b128), then read back as before.  No LDS-DMA issue cost, no manual waits (the compiler tracks the staging registers;
-  // LDS operations of one wave execute in order), the next block's loads are in flight one whole block ahead.
-  constexpr bool kFL3 = kFL && (OPT & 65536) != 0;
-  static_assert(!kAggMax || (kFL && !kFL3), "OPT bit 19 (max aggregation) is written for the production gather path");
-  if constexpr (kFL3) {
-    const int rsel = lane >> 3, cc = lane & 7;
-    auto swz = [](int r) { return ((r >> 1) & 3) | (((r >> 4) & 1) << 2); };
-    int src_off[4];
-#pragma unroll
-    for (int p4 = 0; p4 < 4; ++p4) {
-      const int r = 8 * p4 + rsel;
-      const int jr = __shfl(j, r, 64);
-      src_off[p4] = jr * (4 * H * 4) + ((cc ^ swz(r)) * 16);
-    }
-    const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(node4), 0, 0xffffffff, 0x00020000);
-    unsigned char* const ua0 = reinterpret_cast<unsigned char*>(wbuf + BUF + (PP * wave) * 512);           // rows 0-15
-    unsigned char* const ua1 = reinterpret_cast<unsigned char*>(wbuf + BUF + PLANE + (PP * wave) * 512);   // rows 16-31
-    const unsigned char* const rd_a = ((l31 & 16) ? ua1 : ua0) + (l31 & 15) * 128;
-    int rd_pos[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) rd_pos[g] = ((2 * g + hh) ^ swz(l31)) * 16;
-    const int b_voff = i_node * (4 * H * 4) + hh * 16;
-    v4f stg_a[4], stg_v[4], bh_q[4];
-#define FUSED_FL3_LOAD(dst, table, nb_)                                                                                    \
-  {                                                                                                                       \
-    _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4)                                                                      \
-      dst[p4] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_n, src_off[p4], (table) * H * 4 + (nb_) * 128, 0)); \
-  }
-#define FUSED_FL3_TRANSPOSE(src, dst)                                                                                      \
-  {                                                                                                                       \
-    _Pragma("unroll") for (int p4 = 0; p4 < 4; ++p4)                                                                      \
-      *reinterpret_cast<v4f*>(((p4 >> 1) ? ua1 : ua0) + (p4 & 1) * 1024 + lane * 16) = src[p4];                           \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const v4f*>(rd_a + rd_pos[g]);                \
-  }
-#define FUSED_FL3_B(nb_)                                                                                                   \
-  {                                                                                                                       \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                                         \
-      bh_q[g] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_n, b_voff, (3 * H + 32 * (nb_) + 8 * g) * 4, 0)); \
-  }
-    FUSED_FL3_B(0)
-    FUSED_FL3_LOAD(stg_a, 2, 0)
-    if constexpr (TAIL != 1) { FUSED_FL3_LOAD(stg_v, 1, 0) }
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const int nq = nb & 1;
-      v4f ah_q[4], vh_q[4];
-      v2f sg_q[4][2];
-      FUSED_FL3_TRANSPOSE(stg_a, ah_q)
-      if (nb + 1 < 8) { FUSED_FL3_LOAD(stg_a, 2, nb + 1) }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int fb = 32 * nb + 8 * g + 4 * hh;
-        const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const int r = 4 * g + 2 * h2;
-          v2f ce;
-          if constexpr (T::kScaled && !L0) ce = DIFUSCO_PAIR(acc1[nb], r) * v2f{inv1, inv1} + DIFUSCO_PAIR(bc, 2 * h2);
-          else ce = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(bc, 2 * h2);
-          const v2f ev = (DIFUSCO_PAIR(ah_q[g], 2 * h2) + DIFUSCO_PAIR(bh_q[g], 2 * h2)) + ce;
-          acc1[nb][r] = ev[0];
-          acc1[nb][r + 1] = ev[1];
-          s1k[h2] += ev;
-          if constexpr (TAIL != 1) sg_q[g][h2] = fast_sigmoid2(ev);
-        }
-      }
-      if (nb + 1 < 8) { FUSED_FL3_B(nb + 1) }
-      if constexpr (TAIL != 1) {
-        FUSED_FL3_TRANSPOSE(stg_v, vh_q)
-        if (nb + 1 < 8) { FUSED_FL3_LOAD(stg_v, 1, nb + 1) }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          v4f m;
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const v2f sg = sg_q[g][h2] * DIFUSCO_PAIR(vh_q[g], 2 * h2);
-            m[2 * h2] = valid ? sg[0] : 0.0f;
-            m[2 * h2 + 1] = valid ? sg[1] : 0.0f;
-          }
-          *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
-        }
-        if (nq == 1) { FUSED_AGG_ROUND(nb >> 1) }
-      }
-    }
-#undef FUSED_FL3_LOAD
-#undef FUSED_FL3_TRANSPOSE
-#undef FUSED_FL3_B
-  } else
+  static_assert(!kAggMax || kFL, "OPT bit 19 (max aggregation) is written for the production gather path");
   if constexpr (kFL) {
     const int rsel = lane >> 3, cc = lane & 7;
     auto swz = [](int r) { return ((r >> 1) & 3) | (((r >> 4) & 1) << 2); };
@@ -816,19 +721,18 @@ _Pragma("unroll")                                                               
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int fb = 32 * nb + 8 * g + 4 * hh;
-        const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const int r = 4 * g + 2 * h2;
-          v2f ce;
-          if constexpr (T::kScaled && !L0) ce = DIFUSCO_PAIR(acc1[nb], r) * v2f{inv1, inv1} + DIFUSCO_PAIR(bc, 2 * h2);
-          else ce = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(bc, 2 * h2);
-          const v2f ev = (DIFUSCO_PAIR(ah_q[g], 2 * h2) + DIFUSCO_PAIR(bh_[nb & 1][g], 2 * h2)) + ce;
+          // e' log2(e) = (C e) inv1 + (A h[j] + b_A + b_C) log2(e) + B h[i] log2(e)      (layer 0: the accumulators hold C e_in log2(e))
+          v2f ev;
+          if constexpr (!L0) ev = DIFUSCO_PAIR(acc1[nb], r) * v2f{inv1, inv1} + DIFUSCO_PAIR(ah_q[g], 2 * h2);
+          else ev = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(ah_q[g], 2 * h2);
+          ev = ev + DIFUSCO_PAIR(bh_[nb & 1][g], 2 * h2);
           acc1[nb][r] = ev[0];
           acc1[nb][r + 1] = ev[1];
           s1k[h2] += ev;
-          if constexpr (TAIL != 1) sg_q[g][h2] = fast_sigmoid2(ev);
+          if constexpr (TAIL != 1) sg_q[g][h2] = sigmoid2_log2e(ev);
         }
       }
       if constexpr (TAIL != 1) {
@@ -881,14 +785,9 @@ _Pragma("unroll")                                                               
 #undef FUSED_FL_B
   } else {
   FUSED_GATHER(0, 0)
-  if constexpr (kG2) { FUSED_GATHER(1, 1) }
 #pragma unroll
   for (int b = 0; b < 16; ++b) {             // batch b: block nb = b >> 1, quads g = 2 (b & 1) + {0, 1}
-    if constexpr (kG2) {
-      if (b + 2 < 16) {
-        if ((b + 2) % 3 == 0) FUSED_GATHER(b + 2, 0) else if ((b + 2) % 3 == 1) FUSED_GATHER(b + 2, 1) else FUSED_GATHER(b + 2, 2)
-      }
-    } else if (b + 1 < 16) {
+    if (b + 1 < 16) {
       if (((b + 1) & 1) == 0) FUSED_GATHER(b + 1, 0) else FUSED_GATHER(b + 1, 1)
     }
     if constexpr ((OPT & 256) != 0) __builtin_amdgcn_sched_barrier(0);
@@ -897,35 +796,23 @@ _Pragma("unroll")                                                               
     for (int q2 = 0; q2 < 2; ++q2) {
       const int g = 2 * (b & 1) + q2;
       const int fb = 32 * nb + 8 * g + 4 * hh;
-      const v4f bc = *reinterpret_cast<const v4f*>(prm + P_BC * H + fb);
       const v4f ah = ga[b % GD][q2][0], bh = ga[b % GD][q2][1], vh = ga[b % GD][q2][2];
       v4f m;
-      if constexpr (kPk) {
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const int r = 4 * g + 2 * h2;
-          v2f ce;
-          if constexpr (T::kScaled && !L0) ce = DIFUSCO_PAIR(acc1[nb], r) * v2f{inv1, inv1} + DIFUSCO_PAIR(bc, 2 * h2);
-          else ce = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(bc, 2 * h2);
-          const v2f ev = (DIFUSCO_PAIR(ah, 2 * h2) + DIFUSCO_PAIR(bh, 2 * h2)) + ce;
-          acc1[nb][r] = ev[0];
-          acc1[nb][r + 1] = ev[1];
-          s1k[h2] += ev;
-          if constexpr (TAIL != 1) {
-            const v2f sg = fast_sigmoid2(ev) * DIFUSCO_PAIR(vh, 2 * h2);
-            m[2 * h2] = valid ? sg[0] : 0.0f;
-            m[2 * h2 + 1] = valid ? sg[1] : 0.0f;
-          }
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int r = 4 * g + 2 * h2;
+        v2f ev;      // (the arithmetic of the full-line branch above, operation for operation: bit-identical results)
+        if constexpr (!L0) ev = DIFUSCO_PAIR(acc1[nb], r) * v2f{inv1, inv1} + DIFUSCO_PAIR(ah, 2 * h2);
+        else ev = DIFUSCO_PAIR(acc1[nb], r) + DIFUSCO_PAIR(ah, 2 * h2);
+        ev = ev + DIFUSCO_PAIR(bh, 2 * h2);
+        acc1[nb][r] = ev[0];
+        acc1[nb][r + 1] = ev[1];
+        s1k[h2] += ev;
+        if constexpr (TAIL != 1) {
+          const v2f sg = sigmoid2_log2e(ev) * DIFUSCO_PAIR(vh, 2 * h2);
+          m[2 * h2] = valid ? sg[0] : 0.0f;
+          m[2 * h2 + 1] = valid ? sg[1] : 0.0f;
         }
-      } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float ce = (T::kScaled && !L0) ? acc1[nb][4 * g + q] * inv1 + bc[q] : acc1[nb][4 * g + q] + bc[q];
-        const float ev = (ah[q] + bh[q]) + ce;
-        acc1[nb][4 * g + q] = ev;
-        if constexpr (kPart) s1p[q] += ev; else s1 += ev;
-        if constexpr (TAIL != 1) m[q] = valid ? fast_sigmoid(ev) * vh[q] : 0.0f;   // (select: pad lanes may hold anything)
-      }
       }
       if constexpr (TAIL != 1) *reinterpret_cast<v4f*>(scr + l31 * SCR_STRIDE + nq * 32 + 8 * g + 4 * hh) = m;
     }
@@ -956,14 +843,14 @@ _Pragma("unroll")                                                               
     continue;
   }
 
-  // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU
+  // LayerNorm_e (two pass on registers), ReLU, + t, LayerNorm_o, SiLU.  Element-wise arithmetic on register pairs (v2f): with the
+  // packed-fp32 target feature off (build.py) every pair operation becomes two plain instructions on adjacent registers.
   constexpr float inv_h = 1.0f / 256.0f;
   constexpr bool skip_math = (ablate & 4) != 0;
-  if constexpr (kPk) s1 = (s1k[0][0] + s1k[0][1]) + (s1k[1][0] + s1k[1][1]);
-  else if constexpr (kPart) s1 = (s1p[0] + s1p[1]) + (s1p[2] + s1p[3]);
+  s1 = (s1k[0][0] + s1k[0][1]) + (s1k[1][0] + s1k[1][1]);
   const float mean1 = skip_math ? 0.0f : (s1 + __shfl_xor(s1, 32, 64)) * inv_h;
-  float q1 = 0.0f, q1p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if constexpr (kPk) {
+  float q1;
+  {
     v2f qk[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
     const v2f mean1k = {mean1, mean1};
 #pragma unroll
@@ -976,19 +863,10 @@ _Pragma("unroll")                                                               
         qk[pr & 1] += d * d;
       }
     q1 = (qk[0][0] + qk[0][1]) + (qk[1][0] + qk[1][1]);
-  } else {
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d = acc1[nb][r] - mean1;
-      acc1[nb][r] = d;
-      if constexpr (kPart) q1p[r & 3] += d * d; else q1 += d * d;
-    }
-  if constexpr (kPart) q1 = (q1p[0] + q1p[1]) + (q1p[2] + q1p[3]);
   }
-  const float rstd1 = __builtin_amdgcn_rsqf((q1 + __shfl_xor(q1, 32, 64)) * inv_h + 1e-5f);
-  float s2 = 0.0f, s2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  // (the values are e' log2(e): the variance carries log2(e)^2, and so does the epsilon - the normalised value is that of e')
+  const float rstd1 = __builtin_amdgcn_rsqf((q1 + __shfl_xor(q1, 32, 64)) * inv_h + kEps1);
+  float s2 = 0.0f;
   v2f s2k[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
   if constexpr (!skip_math) {
 #pragma unroll
@@ -998,33 +876,24 @@ _Pragma("unroll")                                                               
         const int fb = 32 * nb + 8 * g + 4 * hh;
         const v4f ge = *reinterpret_cast<const v4f*>(prm + P_GE * H + fb);
         const v4f be = *reinterpret_cast<const v4f*>(prm + P_BE * H + fb);
-        const v4f tb = *reinterpret_cast<const v4f*>(prm + P_T * H + fb);
-        if constexpr (kPk) {
+        v4f tb;
+        if constexpr (!NOTB) tb = *reinterpret_cast<const v4f*>(prm + P_T * H + fb);
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const int r = 4 * g + 2 * h2;
-            v2f y = DIFUSCO_PAIR(acc1[nb], r) * v2f{rstd1, rstd1} * DIFUSCO_PAIR(ge, 2 * h2) + DIFUSCO_PAIR(be, 2 * h2);
-            y = v2f{y[0] > 0.0f ? y[0] : 0.0f, y[1] > 0.0f ? y[1] : 0.0f} + DIFUSCO_PAIR(tb, 2 * h2);
-            acc1[nb][r] = y[0];
-            acc1[nb][r + 1] = y[1];
-            s2k[h2] += y;
-          }
-        } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float y = acc1[nb][4 * g + q] * rstd1 * ge[q] + be[q];
-          y = (y > 0.0f ? y : 0.0f) + tb[q];
-          acc1[nb][4 * g + q] = y;
-          if constexpr (kPart) s2p[q] += y; else s2 += y;
-        }
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int r = 4 * g + 2 * h2;
+          v2f y = DIFUSCO_PAIR(acc1[nb], r) * v2f{rstd1, rstd1} * DIFUSCO_PAIR(ge, 2 * h2) + DIFUSCO_PAIR(be, 2 * h2);
+          y = v2f{y[0] > 0.0f ? y[0] : 0.0f, y[1] > 0.0f ? y[1] : 0.0f};
+          if constexpr (!NOTB) y = y + DIFUSCO_PAIR(tb, 2 * h2);      // (NOTB: the layer has no time bias on e - MIS, gnn_encoder.py:447)
+          acc1[nb][r] = y[0];
+          acc1[nb][r + 1] = y[1];
+          s2k[h2] += y;
         }
       }
   }
-  if constexpr (kPk) s2 = (s2k[0][0] + s2k[0][1]) + (s2k[1][0] + s2k[1][1]);
-  else if constexpr (kPart) s2 = (s2p[0] + s2p[1]) + (s2p[2] + s2p[3]);
+  s2 = (s2k[0][0] + s2k[0][1]) + (s2k[1][0] + s2k[1][1]);
   const float mean2 = (s2 + __shfl_xor(s2, 32, 64)) * inv_h;
-  float q2s = 0.0f, q2p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if constexpr (kPk) {
+  float q2s;
+  {
     v2f qk[2] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
     const v2f mean2k = {mean2, mean2};
 #pragma unroll
@@ -1037,16 +906,6 @@ _Pragma("unroll")                                                               
         qk[pr & 1] += d * d;
       }
     q2s = (qk[0][0] + qk[0][1]) + (qk[1][0] + qk[1][1]);
-  } else {
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d = acc1[nb][r] - mean2;
-      acc1[nb][r] = d;
-      if constexpr (kPart) q2p[r & 3] += d * d; else q2s += d * d;
-    }
-  if constexpr (kPart) q2s = (q2p[0] + q2p[1]) + (q2p[2] + q2p[3]);
   }
   const float rstd2 = __builtin_amdgcn_rsqf((q2s + __shfl_xor(q2s, 32, 64)) * inv_h + 1e-5f);
 
@@ -1056,39 +915,22 @@ _Pragma("unroll")                                                               
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) {
-      float a8[8], m8[8];      // (m8: kMixSplit - the activation is a8 * m8, multiplied inside the split)
+      float a8[8];
 #pragma unroll
       for (int g2 = 0; g2 < 2; ++g2) {
         const int g = 2 * rg + g2;
         const int fb = 32 * nb + 8 * g + 4 * hh;
         const v4f go = *reinterpret_cast<const v4f*>(prm + P_GO * H + fb);
         const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BO * H + fb);
-        if constexpr (kPk && !skip_math) {
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const v2f z = DIFUSCO_PAIR(acc1[nb], 4 * g + 2 * h2) * v2f{rstd2, rstd2} * DIFUSCO_PAIR(go, 2 * h2) + DIFUSCO_PAIR(bo, 2 * h2);
-            if constexpr (kMixSplit) {
-              const v2f sg = fast_sigmoid2s(z, nsig);
-              a8[4 * g2 + 2 * h2] = z[0];
-              a8[4 * g2 + 2 * h2 + 1] = z[1];
-              m8[4 * g2 + 2 * h2] = sg[0];
-              m8[4 * g2 + 2 * h2 + 1] = sg[1];
-            } else {
-              const v2f a = z * fast_sigmoid2s(z, nsig);
-              a8[4 * g2 + 2 * h2] = a[0];
-              a8[4 * g2 + 2 * h2 + 1] = a[1];
-            }
-          }
-        } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float z = acc1[nb][4 * g + q] * rstd2 * go[q] + bo[q];
-          a8[4 * g2 + q] = skip_math ? z : z * fast_sigmoid_s(z, nsig);
-        }
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const v2f z = DIFUSCO_PAIR(acc1[nb], 4 * g + 2 * h2) * v2f{rstd2, rstd2} * DIFUSCO_PAIR(go, 2 * h2) + DIFUSCO_PAIR(bo, 2 * h2);
+          const v2f a = skip_math ? z : silu2_log2e(z, s_den);      // z log2(e) -> SiLU(z) log2(e) 2^ka
+          a8[4 * g2 + 2 * h2] = a[0];
+          a8[4 * g2 + 2 * h2 + 1] = a[1];
         }
       }
-      if constexpr (kMixSplit && kPk && !skip_math) split8_mul<T>(a8, m8, ah_[nb][rg], al_[nb][rg]);
-      else split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
+      split8<T>(a8, ah_[nb][rg], al_[nb][rg]);
     }
 
   if constexpr ((OPT & 512) != 0) __builtin_amdgcn_s_setprio(0);
@@ -1191,21 +1033,11 @@ _Pragma("unroll")                                                               
           const int fo = 64 * qt + 32 * nbp + 8 * g + 4 * hh;
           const v4f bo = *reinterpret_cast<const v4f*>(prm + P_BOUT * H + fo);
           v4f v;
-          if constexpr (kPk) {
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-              v2f o;
-              if constexpr (T::kScaled)
-                o = DIFUSCO_PAIR(ein[nbp][g], 2 * h2) + (DIFUSCO_PAIR(acc2[nbp], 4 * g + 2 * h2) * v2f{inv2, inv2} + DIFUSCO_PAIR(bo, 2 * h2));
-              else
-                o = DIFUSCO_PAIR(ein[nbp][g], 2 * h2) + (DIFUSCO_PAIR(acc2[nbp], 4 * g + 2 * h2) + DIFUSCO_PAIR(bo, 2 * h2));
-              v[2 * h2] = o[0];
-              v[2 * h2 + 1] = o[1];
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              v[q] = ein[nbp][g][q] + (T::kScaled ? acc2[nbp][4 * g + q] * inv2 + bo[q] : acc2[nbp][4 * g + q] + bo[q]);
+          for (int h2 = 0; h2 < 2; ++h2) {      // inv2 = 2^-(ko+ka) / log2(e) (unscaled planes: 1 / log2(e)): one multiply-add either way
+            const v2f o = DIFUSCO_PAIR(ein[nbp][g], 2 * h2) + (DIFUSCO_PAIR(acc2[nbp], 4 * g + 2 * h2) * v2f{inv2, inv2} + DIFUSCO_PAIR(bo, 2 * h2));
+            v[2 * h2] = o[0];
+            v[2 * h2 + 1] = o[1];
           }
           st_e(((4 * qt + 2 * nbp + (g >> 1)) * 512 + (g & 1) * 256), v);
           if constexpr (T::kScaled && !GNP) {      // (v_max3_f32 with |.| source modifiers)
@@ -1281,7 +1113,7 @@ _Pragma("unroll")                                                               
 #define FUSED_OPT_R2 3955    // round 2's production set (register gathers): what the gather / neighbour-sum ablation masks are written for
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
 
-template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0, int OPT = 0>
+template <typename T, int ABL, int NW, bool L0 = false, bool GNP = false, int TAIL = 0, int OPT = FUSED_OPT_R2, bool NOTB = false>
 hipError_t launch_fused_t(float* e, const float* node4, const int* row, const int* col, int n_edges,
                                  const unsigned short* c_planes, const unsigned short* o_planes, long long plane_stride,
                                  const float* b_c, const float* g_e, const float* b_e, const float* tbias,
@@ -1291,7 +1123,7 @@ hipError_t launch_fused_t(float* e, const float* node4, const int* row, const in
                                  float* etmax_out) {
   static std::atomic<unsigned long long> attr_devices{0};      // per kernel instantiation: devices already configured
   {
-    hipError_t er = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL, OPT>),
+    hipError_t er = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL, OPT, NOTB>),
                                            160 * 1024);
     if (er != hipSuccess) return er;
   }
@@ -1310,7 +1142,7 @@ hipError_t launch_fused_t(float* e, const float* node4, const int* row, const in
     if (grid > (unsigned)r) grid = (unsigned)r;
   }
   // profiling builds: FUSED_LDS_PAD extra bytes of dynamic LDS lower the number of co-resident workgroups per CU
-  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL, OPT>), dim3(grid), dim3(64 * WV),
+  hipLaunchKernelGGL((edge_layer_fused_kernel<T, ABL, NW, L0, GNP, TAIL, OPT, NOTB>), dim3(grid), dim3(64 * WV),
                      fused::Geo<NW>::LDS_TOTAL + FUSED_LDS_PAD, stream,
                      e, node4, row, col, n_edges, c_planes, o_planes, plane_stride, b_c, g_e, b_e, tbias, g_o, b_o, b_out,
                      time_on_edge, part, direct, FUSED_DBG, l0_table, l0_x, l0_perm, gn_tile, scales, etmax_in, etmax_out, FUSED_START_DELAY);
@@ -1319,27 +1151,18 @@ hipError_t launch_fused_t(float* e, const float* node4, const int* row, const in
 
 // production geometry, no ablation.  Profiling builds (-DDIFUSCO_PROFILING, libdifusco_hip_prof.so) also hold the A/B
 // variants of the scheduling options, selected by g_fused_opt; the production library has the production set only.
-template <typename T, bool L0, bool GNP, int TAIL, typename... A>
+template <typename T, bool L0, bool GNP, int TAIL, bool NOTB = false, typename... A>
 hipError_t launch_fused_opt(A... args) {
 #ifndef DIFUSCO_PROFILING
-  return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
+  return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT, NOTB>(args...);
 #else
-  switch (g_fused_opt) {
-    case 0: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 0>(args...);
-    case 115: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 115>(args...);      // (A/B: e stream by 64-bit lane addresses)
-    case 371: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 371>(args...);      // (A/B: no raised issue priority)
-    case 883: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 883>(args...);      // (A/B: GEMM 1 slabs of e non-temporal too)
-    case 1907: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 1907>(args...);    // (A/B: scalar element-wise arithmetic)
-    case 8051: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 8051>(args...);    // (A/B: production + persistent workgroups)
-    case 12147: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 12147>(args...);  // (A/B: production + gathers two batches ahead)
-    case 3955: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 3955>(args...);    // (A/B: round 2's production: register gathers)
-    case 53107: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 53107>(args...);  // (A/B: ... + two units, counted waits)
-    case 19827: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 19827>(args...);  // (A/B: production without the raised issue priority)
-    case 20339: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 20339>(args...);  // (A/B: round 3's production: no neighbour-sum fast path)
-    case 150899: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 150899>(args...);  // (A/B: production without the raised issue priority)
-    case 85875: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 85875>(args...);  // (A/B: full-line gathers through staging registers)
-    case 413555: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 413555>(args...);  // (A/B: production + planes straight from the factors, bit 18)
-    default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT>(args...);
+  switch (g_fused_opt) {      // (the variants without bits 6 / 11 - serial sums, scalar element-wise code - and bits 13, 16, 18 were removed in round 5)
+    case 8051 + 143360: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 4096, NOTB>(args...);    // (A/B: production + persistent workgroups)
+    case 3955: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 3955, NOTB>(args...);      // (A/B: round 2's production: register gathers)
+    case 53107 + 131072: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 32768, NOTB>(args...);  // (A/B: ... + two gather units, counted waits)
+    case 20339: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 20339, NOTB>(args...);    // (A/B: round 3's production: no neighbour-sum fast path)
+    case 150899: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 150899, NOTB>(args...);  // (A/B: production without the raised issue priority)
+    default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT, NOTB>(args...);
   }
 #endif
 }
@@ -1367,8 +1190,9 @@ hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS);      // profiling
 template <typename T>
 hipError_t launch_fused_kind(int kind, FUSED_KIND_PARAMS) {
   switch (kind) {
-    case 0: return launch_fused_opt<T, false, false, 0>(FUSED_KIND_ARGS);
-    case 1: return launch_fused_opt<T, true, false, 0>(FUSED_KIND_ARGS);
+    // (a layer without a time bias on e - MIS, gnn_encoder.py:447 - takes the NOTB instantiation: no bias reads, no adds)
+    case 0: return time_on_edge ? launch_fused_opt<T, false, false, 0>(FUSED_KIND_ARGS) : launch_fused_opt<T, false, false, 0, true>(FUSED_KIND_ARGS);
+    case 1: return time_on_edge ? launch_fused_opt<T, true, false, 0>(FUSED_KIND_ARGS) : launch_fused_opt<T, true, false, 0, true>(FUSED_KIND_ARGS);
     case 2: return launch_fused_opt<T, false, true, 1>(FUSED_KIND_ARGS);
     case 3: return launch_fused_opt<T, false, false, 2>(FUSED_KIND_ARGS);
     case 4: return launch_fused_t<T, 0, FUSED_NW, false, false, 0, FUSED_OPT_R2>(FUSED_KIND_ARGS);

@@ -100,6 +100,9 @@ extern unsigned long long* g_fused_dbg;
 #endif
 // h_in: the node state the update is added to (nullptr = h itself, in place; layer 0 of a step with prepared state reads the
 // prepared h0 and writes the workspace h)
+// node4 [n, 4*256] (U | V | A | B rows as the reference defines them) -> out: U | V copied, (A + b_c) log2(e), B log2(e): the form in
+// which the fused edge kernel reads its neighbour tables (difusco_hip.h, ABI 11 note)
+hipError_t launch_fuse_node_tables(const float* node4, const float* b_c, int n_nodes, float* out, hipStream_t stream);
 hipError_t launch_node_finalize(int n_nodes, int n_edges, const int* rowptr, const float* node4, const float* part,
                                 const float* direct, float* h, const float* nh_w, const float* nh_b,
                                 const float* tbias, int time_on_edge, float* row_scale, hipStream_t stream,

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void node_linear_kernel(const float* __rest
     float wv[4], bv[4], rs[16];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-      wv[nb] = T::kScaled ? w_inv[f0 + nb * 32 + l31] : 1.0f;
+      wv[nb] = w_inv != nullptr ? w_inv[f0 + nb * 32 + l31] : 1.0f;      // (fp16 planes: 2^-k_f; fused path: times log2(e) on the A | B columns)
       bv[nb] = bias != nullptr ? bias[f0 + nb * 32 + l31] : 0.0f;
     }
 #pragma unroll

@@ -82,7 +82,7 @@ class DenoiseEngine:
                     "use backend='ctypes' with the profiling library / DIFUSCO_HIP_LIBRARY")
             self._ops = torch_ops.load()
         self._ws = {}               # HIP stream -> workspace tensor
-        self._tbias = {}            # t -> [n_layers, hidden] time-bias rows on the device (prepare_times / lazily per t)
+        self._tbias = {}            # (HIP stream, t) -> [n_layers, hidden] time-bias rows on the device (prepare_times)
         self.calls = 0
 
     # ---- workspace -----------------------------------------------------------------------------
@@ -109,7 +109,10 @@ class DenoiseEngine:
     def prepare_times(self, ts) -> None:
         """Time-bias rows of every diffusion time in ``ts`` (e.g. the 50 steps of a schedule) in ONE launch; ``step`` then
         passes the row block of its ``t`` instead of running the time MLP (``gnn_encoder.py:396,329-337``)."""
-        todo = sorted({float(t) for t in ts} - set(self._tbias))
+        # (cached per HIP stream, like the workspace: the rows are produced asynchronously on the current stream, and a step on
+        #  another stream must not read them before that launch has finished)
+        sid = torch.cuda.current_stream(self.device).cuda_stream
+        todo = sorted({float(t) for t in ts} - {t for (s_, t) in self._tbias if s_ == sid})
         if not todo:
             return
         if self.backend == "torch":
@@ -124,13 +127,19 @@ class DenoiseEngine:
         if len(self._tbias) > 4096:
             self._tbias.clear()
         for i, t in enumerate(todo):
-            self._tbias[t] = out[i]
+            self._tbias[(sid, t)] = out[i]
+
+    def _uses_prepared(self, g: CsrGraph) -> bool:
+        """Will ``difusco_denoise_step`` read a prepared buffer for a call on graph ``g``?  The C side's ``fused`` predicate
+        (api.hip): H = 256, a split precision with a fused kernel, edges, and not (max aggregation with >= 2^20 nodes)."""
+        return (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_edges > 0
+                and not (self.aggregation == "max" and g.n_nodes >= (1 << 20)))
 
     def prepare(self, g: CsrGraph, points: torch.Tensor) -> Optional[torch.Tensor]:
         """The step-invariant part of a TSP step for (these weights, this graph, these coordinates) - node embedding,
         layer 0's node linear, the two-row edge-input table (``difusco_prepare``) - as an opaque device buffer to hand to
         ``step(prepared=...)``.  None when the fused path does not apply (the step then computes everything itself)."""
-        if not (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_edges > 0):
+        if not self._uses_prepared(g):      # (a buffer for a call that would ignore it is never handed out)
             return None
         pts = points.to(self.device, dtype=torch.float32).contiguous()
         if pts.numel() != 2 * g.n_nodes:
@@ -178,8 +187,10 @@ class DenoiseEngine:
         rows = g.n_edges if task == _lib.TASK_TSP else g.n_nodes
         if xt.numel() != rows:
             raise ValueError(f"xt has {xt.numel()} elements, the graph has {rows} output rows")
-        if prepared is not None and task == _lib.TASK_TSP:
+        if prepared is not None and task == _lib.TASK_TSP and self._uses_prepared(g):
             points = None      # (h0 and layer 0's node rows come from the prepared buffer)
+        elif prepared is not None and not self._uses_prepared(g):
+            prepared = None    # (the step would ignore it and needs the points: e.g. the engine was switched to the unfused sequence)
         if points is not None:
             points = points.to(dev, dtype=torch.float32).contiguous()
             if points.numel() != 2 * g.n_nodes:
@@ -196,7 +207,7 @@ class DenoiseEngine:
         pred = torch.empty((rows, 2) if C == 2 else (rows,), dtype=torch.float32, device=dev) if want_pred else None
         prob = torch.empty(rows, dtype=torch.float32, device=dev) if (want_prob and C == 2) else None
         ws = self._workspace(g)
-        tbias = self._tbias.get(float(t))
+        tbias = self._tbias.get((torch.cuda.current_stream(dev).cuda_stream, float(t)))
         # the Philox key and offset are 63-bit on both backends (the torch op schema carries signed 64-bit ints)
         seed, offset = int(seed) & (2 ** 63 - 1), int(offset) & (2 ** 63 - 1)
         if self.backend == "torch":

@@ -112,6 +112,7 @@ class COMetaModel:
         if g is None:
             if len(self._graph_cache) > 8:
                 self._graph_cache.clear()
+                self._prep_cache.clear()      # (prepared buffers hold their graphs alive)
             g = build_csr(edge_index, int(num_nodes), self.device, points=points if self.reorder_nodes else None)
             self._graph_cache[key] = (g, edge_index)   # keep edge_index alive: data_ptr stays unique
             return g
@@ -131,10 +132,11 @@ class COMetaModel:
         if not self.prepare or points is None:
             return None
         version = 0 if points.is_inference() else points._version
-        key = (id(g), points.data_ptr(), tuple(points.shape), version)
+        # (per HIP stream: the buffer is produced asynchronously on the stream that is current here)
+        key = (id(g), points.data_ptr(), tuple(points.shape), version, torch.cuda.current_stream(self.device).cuda_stream)
         hit = self._prep_cache.get(key)
         if hit is None:
-            if len(self._prep_cache) > 8:
+            if len(self._prep_cache) >= 2:      # a sampling loop reuses ONE entry; each pins 5 N H floats + the graph + the points
                 self._prep_cache.clear()
             hit = (self.model.prepare(g, points), g, points)      # keep g / points alive: id() and data_ptr() stay unique
             self._prep_cache[key] = hit

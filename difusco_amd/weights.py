@@ -95,14 +95,26 @@ LOG2E = 1.4426950408889634
 
 def fused_scales(w_c: torch.Tensor, w_o: torch.Tensor, g_o: torch.Tensor, b_o: torch.Tensor) -> torch.Tensor:
     """The 8-float operand-scale record of the fused edge kernel (include/difusco_hip.h: DIFUSCO_WL_FUSED_SCALES):
-    {2^-kc, 2^-(ko+ka), 2^ka, -log2(e) 2^-ka, 0...}.  ka comes from a bound that needs no data: the kernel's GEMM 2 operand is
-    a = SiLU(z), z = LN(y) g_o + b_o with |LN(y)| <= sqrt(H - 1) < 16, and |SiLU(z)| <= max(|z|, 0.2785)."""
+    {log2(e) 2^-kc, 2^-(ko+ka) / log2(e), log2(e), 2^-ka, 0...}.  ka comes from a bound that needs no data: the kernel's GEMM 2
+    operand is a log2(e), a = SiLU(z), z = LN(y) g_o + b_o with |LN(y)| <= sqrt(H - 1) < 16, and |SiLU(z)| <= max(|z|, 0.2785)."""
     inv_c = 1.0 / pow2_scale(w_c.detach().float().abs().amax().reshape(1))[0]      # the per-matrix scales of split_planes
     inv_o = 1.0 / pow2_scale(w_o.detach().float().abs().amax().reshape(1))[0]
-    bound = torch.clamp(16.0 * g_o.detach().float().abs().max() + b_o.detach().float().abs().max(), min=0.2785)
+    c = torch.tensor(LOG2E, dtype=torch.float32)
+    bound = torch.clamp(16.0 * g_o.detach().float().abs().max() + b_o.detach().float().abs().max(), min=0.2785) * c
     sa = pow2_scale(bound.reshape(1))[0]
-    nsig = torch.tensor(-LOG2E, dtype=torch.float32) / sa
-    return torch.stack([inv_c, inv_o / sa, sa, nsig] + [torch.tensor(0.0)] * 4).float()
+    return torch.stack([inv_c * c, (inv_o / sa) / c, c, 1.0 / sa] + [torch.tensor(0.0)] * 4).float()
+
+
+def node4_fused_vectors(state, l: int, hidden: int, planes: torch.Tensor):
+    """Bias [4H] and column scales [2][4H] with which the node linear U | V | A | B produces the rows the FUSED edge kernel reads
+    (include/difusco_hip.h, ABI 11 note): A | B columns in the log2(e) domain, b_C folded into the A columns.  ``planes`` = the
+    packed split planes of the node linear (their tail holds the fp16 row scales 2^-k_f)."""
+    c = torch.tensor(LOG2E, dtype=torch.float32)
+    b = [state[f"layers.{l}.{m}.bias"].float() for m in "UVAB"]
+    bias = torch.cat([b[0], b[1], (b[2] + state[f"layers.{l}.C.bias"].float()) * c, b[3] * c])
+    col = torch.cat([torch.ones(2 * hidden), torch.full((2 * hidden,), LOG2E)]).float()
+    w_inv = plane_scale_inv(planes, 4 * hidden, hidden)
+    return bias, torch.cat([w_inv * col, col])
 
 
 def pack_state_dict(state) -> torch.Tensor:
@@ -134,6 +146,10 @@ def pack_state_dict(state) -> torch.Tensor:
                 t = torch.cat([state[f"layers.{l}.{m}.bias"] for m in "UVAB"], dim=0)
             elif name == "@planes:@node4.weight":
                 t = split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0), per_row=True)
+            elif name == "@node4.fused_bias":
+                t = node4_fused_vectors(state, l, hidden, split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0), per_row=True))[0]
+            elif name == "@node4.fused_scale":
+                t = node4_fused_vectors(state, l, hidden, split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0), per_row=True))[1]
             elif name == "@fused_scales":
                 t = fused_scales(state[f"layers.{l}.C.weight"], state[f"per_layer_out.{l}.2.weight"],
                                  state[f"per_layer_out.{l}.0.weight"], state[f"per_layer_out.{l}.0.bias"])

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DIFUSCO_ABI_VERSION 10
+#define DIFUSCO_ABI_VERSION 11
 
 enum {
   DIFUSCO_OK = 0,
@@ -37,7 +37,9 @@ enum {
 
 enum { DIFUSCO_TASK_TSP = 0, DIFUSCO_TASK_MIS = 1 };            /* edge features | node features only */
 enum { DIFUSCO_CATEGORICAL = 0, DIFUSCO_GAUSSIAN = 1 };
-/* neighbourhood aggregation of the GNN layers (--aggregation, train.py:52; gnn_encoder.py:170-191): every published run uses sum */
+/* neighbourhood aggregation of the GNN layers (--aggregation, train.py:52; gnn_encoder.py:170-191): every published run uses sum.
+ * MAX combines messages with fmaxf, which returns the non-NaN operand: a NaN message is DROPPED where torch.max / segment_csr(max)
+ * would propagate it into h.  A non-finite state still surfaces through e (and DIFUSCO_FLAG_CHECK_FINITE sees it there). */
 enum { DIFUSCO_AGG_SUM = 0, DIFUSCO_AGG_MEAN = 1, DIFUSCO_AGG_MAX = 2 };
 enum {
   DIFUSCO_PREC_FP32 = 0,   /* E-row linears on v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fma chain) */
@@ -85,6 +87,8 @@ enum {                       /* per layer l, index = GLOBAL_COUNT + l*LAYER_COUN
   DIFUSCO_WL_C_PLANES, DIFUSCO_WL_OUT_PLANES, /* split planes of C / per_layer_out[l].2 */
   DIFUSCO_WL_NODE4_PLANES,                    /* split planes of the [4H,H] node linear (U|V|A|B) */
   DIFUSCO_WL_FUSED_SCALES,                    /* 8 floats: operand scales of the fused edge kernel, see below */
+  DIFUSCO_WL_NODE4_FUSED_B,                   /* [4H]   bias of the node linear as the FUSED edge kernel wants its rows, see below (ABI 11) */
+  DIFUSCO_WL_NODE4_FUSED_S,                   /* [2][4H] column scales of the node linear for the fused path: fp16 planes | bf16 planes   */
   DIFUSCO_WL_COUNT
 };
 /* "*_PLANES" entries: the [H,H] weight w decomposed on the host into five 16-bit planes
@@ -100,10 +104,16 @@ enum {                       /* per layer l, index = GLOBAL_COUNT + l*LAYER_COUN
  * (bf16 has the fp32 exponent range).
  * 5*n_out*k 16-bit elements + n_out floats = 2.5*n_out*k + n_out floats of blob space per matrix.  They feed the
  * split-precision MFMA paths selected by difusco_step_args.precision.
- * DIFUSCO_WL_FUSED_SCALES = {2^-kc, 2^-(ko+ka), 2^ka, -log2(e) * 2^-ka, 0, 0, 0, 0}: kc / ko the plane scales of C /
- * per_layer_out[l][2]; 2^ka the scale under which the fused kernel produces the GEMM 2 operand a = SiLU(LN_o(.)), from
+ * DIFUSCO_WL_FUSED_SCALES = {log2(e) 2^-kc, 2^-(ko+ka) / log2(e), log2(e), 2^-ka, 0, 0, 0, 0}: kc / ko the plane scales of C /
+ * per_layer_out[l][2]; 2^ka the scale under which the fused kernel produces the GEMM 2 operand a log2(e), a = SiLU(LN_o(.)), from
  * the bound |a| <= max(16 max|g_o| + max|b_o|, 0.2785) (|LayerNorm| <= sqrt(H-1) < 16).  difusco_amd/weights.py computes
- * all of it (fused_scales); the e operand of GEMM 1 is scaled per 32-edge tile on the device. */
+ * all of it (fused_scales); the e operand of GEMM 1 is scaled per 32-edge tile on the device.
+ * ABI 11, "log2(e) domain": the fused edge kernel carries the gate pre-activation e' = A h[j] + B h[i] + C e + b_C as e' log2(e)
+ * (sigmoid = 1 / (1 + exp2(-.)) without a multiply; LayerNorm is scale invariant).  Its neighbour-table rows node4[:, 2H:4H]
+ * therefore hold (A h + b_A + b_C) log2(e) | (B h + b_B) log2(e): on the fused path the node linear is run with
+ * DIFUSCO_WL_NODE4_FUSED_B = {b_U, b_V, (b_A + b_C) log2(e), b_B log2(e)} as its bias and with the per-column accumulator scales
+ * DIFUSCO_WL_NODE4_FUSED_S (row 0: 2^-k_f of the fp16 planes, times log2(e) on the A | B columns; row 1, unscaled bf16 planes:
+ * 1 | 1 | log2(e) | log2(e)).  The U | V columns are unchanged.  The unfused kernels read node4 as the reference defines it. */
 /* Fills offsets[0 .. GLOBAL_COUNT + n_layers*WL_COUNT) (floats from blob start) and *total_floats.
  * Returns the number of entries, or a negative error. */
 int difusco_weights_layout(int hidden, int n_layers, int out_channels,

@@ -3,7 +3,7 @@ against the CPU oracle on the same seeded inputs and against the committed golde
 
 Tolerances (fp32 path): network outputs 1e-4 absolute (north_star bound; observed values are printed),
 posterior probabilities 1e-4, sampled bits identical for identical uniforms away from ties
-(|u - p| > 1e-4)."""
+(|u - p| > 1e-5)."""
 import ctypes
 import os
 
@@ -361,7 +361,7 @@ def _check_cat(z, i, out, logits, prob, order=None):
     if tt > 0:
         ref_p = z[f"cat{i}_prob"].reshape(-1)
         assert np.abs(prob.cpu().numpy().reshape(-1) - ref_p).max() < TOL
-        safe = np.abs(z[f"cat{i}_uniform"].reshape(-1) - ref_p) > 1e-4
+        safe = np.abs(z[f"cat{i}_uniform"].reshape(-1) - ref_p) > 1e-5
         np.testing.assert_array_equal(out.cpu().numpy().reshape(-1)[safe], z[f"cat{i}_out"].reshape(-1)[safe])
     else:
         assert np.abs(out.cpu().numpy().reshape(-1) - z[f"cat{i}_out"].reshape(-1)).max() < TOL
@@ -467,7 +467,7 @@ def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
         print(f"{prec} H={H} L={Lyr} t={t}: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
         assert e_log < TOL and e_prob < TOL
         if tt > 0:
-            safe = (u - ref_prob.reshape(-1)).abs() > 1e-4
+            safe = (u - ref_prob.reshape(-1)).abs() > 1e-5
             assert torch.equal(out.cpu()[safe], ref_out[safe])
         else:
             assert (out.cpu() - ref_out).abs().max().item() < TOL
@@ -478,7 +478,7 @@ def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
     out, logits, prob = m.categorical_denoise_step(pts.to(dev), xt_s.to(dev), np.array([500]), dev, ei_s.to(dev),
                                                    target_t=np.array([400]), uniform=u_s, return_aux=True)
     assert (logits.cpu() - ref_logits).abs().max().item() < TOL
-    safe = (u_s - ref_prob.reshape(-1)).abs() > 1e-4
+    safe = (u_s - ref_prob.reshape(-1)).abs() > 1e-5
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 
@@ -844,7 +844,7 @@ def test_golden_tsp50_dense_full_width_all_50_steps(dev, golden_dir):
         worst_l = max(worst_l, float(np.abs(logits.cpu().numpy().reshape(ref_logits.shape) - ref_logits).max()))
         if tt > 0:
             worst_p = max(worst_p, float(np.abs(prob.cpu().numpy().reshape(-1) - z["prob"][i].reshape(-1)).max()))
-            safe = np.abs(z["uniform"][i].reshape(-1) - z["prob"][i].reshape(-1)) > 1e-4
+            safe = np.abs(z["uniform"][i].reshape(-1) - z["prob"][i].reshape(-1)) > 1e-5
             np.testing.assert_array_equal(out.cpu().numpy().reshape(-1)[safe], z["out"][i].reshape(-1)[safe])
         else:
             assert np.abs(out.cpu().numpy().reshape(-1) - z["out"][i].reshape(-1)).max() < TOL
@@ -961,7 +961,7 @@ def test_bench_workload_tsp1000_oracle_and_batch(dev):
     e_log, e_prob = (l1.cpu() - ref_logits).abs().max().item(), (p1.cpu() - ref_prob.reshape(-1)).abs().max().item()
     print(f"TSP-1000 K=100 H=256 L=12, one graph vs oracle: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
     assert e_log < TOL and e_prob < TOL
-    safe = (u1 - ref_prob.reshape(-1)).abs() > 1e-4
+    safe = (u1 - ref_prob.reshape(-1)).abs() > 1e-5
     assert torch.equal(out1.cpu()[safe], ref_out[safe])
     # (2) the benched call shape with replicas
     pts = pts1.repeat(G, 1).to(dev)
@@ -1231,7 +1231,7 @@ def test_categorical_step_with_non_binary_xt(dev, H, Lyr, prec):
         print(f"non-binary x_t, TSP {prec} H={H} t={t}: logits L_inf {e_log:.2e}, prob L_inf {e_prob:.2e}")
         assert e_log < TOL and e_prob < TOL
         if tt > 0:
-            safe = (u - ref_prob.reshape(-1)).abs() > 1e-4
+            safe = (u - ref_prob.reshape(-1)).abs() > 1e-5
             assert torch.equal(out.cpu()[safe], ref_out[safe])
     # the binary fast path and the general path agree on binary input (same model, x_t given as 0/1 floats vs ints)
     xb = (xt >= 1).float()
@@ -1249,7 +1249,7 @@ def test_categorical_step_with_non_binary_xt(dev, H, Lyr, prec):
     out, logits, prob = mm.categorical_denoise_step(xm.to(dev), np.array([600]), dev, eim.to(dev), target_t=np.array([560]),
                                                     uniform=um, return_aux=True)
     assert (logits.cpu() - ref_logits).abs().max().item() < TOL and (prob.cpu() - ref_prob.reshape(-1)).abs().max().item() < TOL
-    safe = (um - ref_prob.reshape(-1)).abs() > 1e-4
+    safe = (um - ref_prob.reshape(-1)).abs() > 1e-5
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 

@@ -20,7 +20,9 @@ from oracle import difusco_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4
+TOL = 1e-4          # north_star's bound
+CLASS_TOL = 1e-5    # the bound CLASS of the default engine (fp16x3, 22 significand bits; observed 1e-6 .. 2e-6): VERDICT r4 #5 - a tenfold
+                    # precision regression must not pass silently under the 1e-4 bound
 
 
 @pytest.fixture(scope="module")
@@ -162,8 +164,8 @@ def test_full_depth_oracle_step_tsp500(dev):
                                              uniform=u, return_aux=True)
     e_log, e_prob = (lg.cpu() - ref_logits).abs().max().item(), (pr.cpu() - ref_prob.reshape(-1)).abs().max().item()
     print(f"TSP-500 K=50 H=256 L=12 vs oracle: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
-    assert e_log < TOL and e_prob < TOL
-    safe = (u - ref_prob.reshape(-1)).abs() > 1e-4
+    assert e_log < CLASS_TOL and e_prob < CLASS_TOL
+    safe = (u - ref_prob.reshape(-1)).abs() > 1e-5
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 
@@ -186,8 +188,8 @@ def test_full_depth_oracle_step_mis_er750(dev):
                                              return_aux=True)
     e_log, e_prob = (lg.cpu() - ref_logits).abs().max().item(), (pr.cpu() - ref_prob.reshape(-1)).abs().max().item()
     print(f"MIS ER-750 ({ei.shape[1]} edges) H=256 L=12 vs oracle: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
-    assert e_log < TOL and e_prob < TOL
-    safe = (u - ref_prob.reshape(-1)).abs() > 1e-4
+    assert e_log < CLASS_TOL and e_prob < CLASS_TOL
+    safe = (u - ref_prob.reshape(-1)).abs() > 1e-5
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 
@@ -218,7 +220,7 @@ def test_tsp1000_x64_single_call(dev):
     e_fu = (la - lc).abs().max().item()
     print(f"64 x TSP-1000 in one call (E = {E}): fused vs unfused logits L_inf {e_fu:.3e}, prob L_inf {(pa - pc).abs().max().item():.3e}")
     assert e_fu < 5e-5 and (pa - pc).abs().max().item() < 5e-5
-    safe = ((u.to(dev) - pa).abs() > 1e-4)
+    safe = ((u.to(dev) - pa).abs() > 1e-5)
     assert torch.equal(a[safe], c[safe])
 
 
@@ -386,8 +388,8 @@ def test_dense_batch_through_the_fused_kernel_vs_oracle(dev, V, B):
     e_log = (lg.cpu().reshape(ref_logits.shape) - ref_logits).abs().max().item()
     e_prob = (pr.cpu().reshape(-1) - ref_prob.reshape(-1)).abs().max().item()
     print(f"dense V={V} B={B} H=256 L=12 (fused layers, per-sample statistics) vs oracle: logits L_inf {e_log:.3e}, prob {e_prob:.3e}")
-    assert e_log < TOL and e_prob < TOL
-    safe = (u.reshape(-1) - ref_prob.reshape(-1)).abs() > 1e-4
+    assert e_log < CLASS_TOL and e_prob < CLASS_TOL
+    safe = (u.reshape(-1) - ref_prob.reshape(-1)).abs() > 1e-5
     assert torch.equal(out.cpu().reshape(-1)[safe], ref_out.reshape(-1)[safe])
     mu = TSPModel(_args("categorical", -1), p, device=dev, fused=False)
     _, lu, pu = mu.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, None, target_t=np.array([tt]),

@@ -302,12 +302,18 @@ def test_fused_scales_record():
     for gmax, bmax in [(1.0, 0.0), (1e-4, 1e-5), (37.0, 5.0)]:
         go, bo = torch.rand(256, generator=g) * gmax, (torch.rand(256, generator=g) - 0.5) * 2 * bmax
         rec = weights.fused_scales(wc, wo, go, bo)
-        inv_c, inv_o_a, sa, nsig = (float(v) for v in rec[:4])
-        assert 2.0 ** 14 <= wc.abs().max().item() / inv_c < 2.0 ** 15
-        bound = max(16 * go.abs().max().item() + bo.abs().max().item(), 0.2785)
-        assert 2.0 ** 14 <= bound * sa < 2.0 ** 15          # |a| 2^ka stays below the fp16 maximum
-        assert np.float32(nsig) == np.float32(-weights.LOG2E) / np.float32(sa)
-        assert 2.0 ** 14 <= wo.abs().max().item() / (inv_o_a * sa) < 2.0 ** 15
+        # {log2(e) 2^-kc, 2^-(ko+ka) / log2(e), log2(e), 2^-ka} (include/difusco_hip.h, ABI 11: the fused kernel's log2(e) domain)
+        c = np.float32(weights.LOG2E)
+        inv_c_c, inv_o_a_c, gmul, s_den = (np.float32(v) for v in rec[:4])
+        assert gmul == c
+        inv_c = float(inv_c_c / c)
+        assert inv_c == 2.0 ** round(np.log2(inv_c)) and 2.0 ** 14 <= wc.abs().max().item() / inv_c < 2.0 ** 15
+        sa = 1.0 / float(s_den)
+        assert sa == 2.0 ** round(np.log2(sa))
+        bound = max(16 * go.abs().max().item() + bo.abs().max().item(), 0.2785) * float(c)
+        assert 2.0 ** 14 <= bound * sa < 2.0 ** 15          # |a| log2(e) 2^ka stays below the fp16 maximum
+        inv_o = float(inv_o_a_c) * sa * float(c)
+        assert abs(inv_o / 2.0 ** round(np.log2(inv_o)) - 1.0) < 2e-7 and 2.0 ** 14 <= wo.abs().max().item() / inv_o < 2.0 ** 15.001
         assert (rec[4:] == 0).all()
 
 
@@ -655,3 +661,26 @@ def test_bench_stdout_line_is_compact():
     assert set(rec["workloads"]) == {"tsp500", "tsp10000", "mis", "tsp50dense"}
     assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] >= 1 and rec["cpu_baseline"]["value"] > 0
     assert rec["full_record"] == "bench_full.json"
+
+
+def test_node4_fused_vectors():
+    """ABI 11: bias / column scales with which the node linear writes the A | B rows in the fused kernel's log2(e) domain."""
+    H = 64
+    st = synthetic_state = __import__("difusco_amd.synthetic", fromlist=["x"]).random_state_dict(H, 2, 2, seed=5)
+    w4 = torch.cat([st[f"layers.1.{m}.weight"] for m in "UVAB"], dim=0)
+    planes = weights.split_planes(w4, per_row=True)
+    bias, scale = weights.node4_fused_vectors(st, 1, H, planes)
+    c = np.float32(weights.LOG2E)
+    assert bias.shape == (4 * H,) and scale.shape == (8 * H,)
+    assert torch.equal(bias[:H], st["layers.1.U.bias"]) and torch.equal(bias[H:2 * H], st["layers.1.V.bias"])
+    assert torch.equal(bias[2 * H:3 * H], (st["layers.1.A.bias"] + st["layers.1.C.bias"]) * c)
+    assert torch.equal(bias[3 * H:], st["layers.1.B.bias"] * c)
+    w_inv = weights.plane_scale_inv(planes, 4 * H, H)
+    assert torch.equal(scale[:2 * H], w_inv[:2 * H]) and torch.equal(scale[2 * H:4 * H], w_inv[2 * H:] * c)
+    assert (scale[4 * H:6 * H] == 1).all() and (scale[6 * H:] == c).all()
+    # and the packed blob holds them where the layout says
+    blob = weights.pack_state_dict(st)
+    off, _ = _lib.weights_layout(H, 2, 2)
+    base = len(_lib.W_GLOBAL) + 1 * len(_lib.W_LAYER)
+    ib, isc = base + _lib.W_LAYER.index("@node4.fused_bias"), base + _lib.W_LAYER.index("@node4.fused_scale")
+    assert torch.equal(blob[off[ib]: off[ib] + 4 * H], bias) and torch.equal(blob[off[isc]: off[isc] + 8 * H], scale)
