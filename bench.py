@@ -42,7 +42,7 @@ def pmc_traffic_bytes(kernel_name, workload, n_edges, variant):
     profiles/r03/pmc_traffic.json (this round's kernel), then profiles/r02/pmc_traffic.json, are keyed by
     "<workload>:<edges on rank 0>:<variant>", i.e. by the exact run the counters were collected on; a run with no profile
     of its own reports None (never another workload's bytes)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         try:
             table = json.load(open(path))
@@ -74,16 +74,20 @@ def pmc_pipe_busy(workload, n_edges, variant, avg_launch_s, n_simd=1024, clock_h
     """Matrix-pipe occupancy of the dominant kernel: SQ_VALU_MFMA_BUSY_CYCLES per launch (rocprofv3 --pmc pass of the same
     run key, profiles/r04/pmc_sq.json; averaged over the launches of a step) / (SIMDs x live average launch time x the
     2.4 GHz the peak is quoted at).  None when that run was never profiled."""
-    path = os.path.join(ROOT, "profiles", "r04", "pmc_sq.json")
-    try:
-        entry = json.load(open(path)).get(f"{workload}:{n_edges}:{variant}")
-    except (OSError, ValueError):
-        entry = None
+    entry, rnd = None, None
+    for rnd in ("r05", "r04"):      # the newest round that profiled this run key
+        try:
+            entry = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_sq.json"))).get(f"{workload}:{n_edges}:{variant}")
+        except (OSError, ValueError):
+            entry = None
+        if entry:
+            break
     if not entry or "SQ_VALU_MFMA_BUSY_CYCLES" not in entry:
         return None
     busy = float(entry["SQ_VALU_MFMA_BUSY_CYCLES"])
     return {"value": busy / (n_simd * avg_launch_s * clock_hz), "mfma_busy_cycles_per_launch": busy,
-            "source": f"profiles/r04/pmc_sq.json[{workload}:{n_edges}:{variant}] (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES) / "
+            "valu_insts_per_launch": entry.get("SQ_INSTS_VALU"),
+            "source": f"profiles/{rnd}/pmc_sq.json[{workload}:{n_edges}:{variant}] (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES) / "
                       f"({n_simd} SIMDs x live avg launch x 2.4 GHz)"}
 
 
@@ -376,7 +380,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="tsp1000", choices=sorted(WORKLOADS),
                     help="tsp1000 = the configuration BASELINE.json's metric is quoted on (default); tsp500, "
                          "tsp10000 (Gaussian diffusion, 1 graph per GPU) and mis (ER-[700,800], p=0.15) are the "
