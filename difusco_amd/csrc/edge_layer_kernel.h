@@ -534,6 +534,8 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   static_assert((OPT & 2048) != 0, "OPT bit 11 is part of every kept instantiation (the scalar form was removed in round 5)");
   // OPT bit 17: fast path of the neighbour sum for tiles that hold ONE centre node (see FUSED_AGG_ROUND); bit-identical
   constexpr bool kAggFast = (OPT & 131072) != 0;
+  // (round 5, with bit 17) the general path tests for a segment start only inside the 8-row groups that hold one
+  constexpr bool kAggQuarter = kAggFast;
   // OPT bit 19 (a SEMANTIC switch, its own instantiations: kinds 8, 9, 11 of launch_fused_kind): aggregation = "max"
   // (gnn_encoder.py:172-173,187-188) - the per-segment pieces part / direct hold the element-wise MAXIMUM of the gated messages
   // instead of their sum (node_finalize_kernel then combines the pieces of a node by maximum); the pad lanes of a launch's last
@@ -595,8 +597,16 @@ _Pragma("unroll")                                                               
           float v[16];                                                                                                       \
 _Pragma("unroll")                                                                                                         \
           for (int k = 0; k < 16; ++k) v[k] = scr[(16 * half + k) * SCR_STRIDE + lane];                                      \
+          /* (round 5) per group of 8 rows: a group that holds no segment start (wave uniform; with K = 100 a tile has at most */ \
+          /* one, so three of its four groups) adds its rows without the per-row tests - same order, bit-identical */         \
 _Pragma("unroll")                                                                                                         \
-          for (int kk = 0; kk < 16; ++kk) {                                                                                  \
+          for (int q8 = 0; q8 < 2; ++q8) {                                                                                   \
+            if (kAggQuarter && ((bnd >> (16 * half + 8 * q8)) & 0xFFu) == 0) {                                               \
+_Pragma("unroll")                                                                                                         \
+              for (int kk = 8 * q8; kk < 8 * q8 + 8; ++kk) { if constexpr (kAggMax) accv = __builtin_fmaxf(accv, v[kk]); else accv += v[kk]; } \
+            } else {                                                                                                         \
+_Pragma("unroll")                                                                                                         \
+          for (int kk = 8 * q8; kk < 8 * q8 + 8; ++kk) {                                                                     \
             const int k = 16 * half + kk;                                                                                    \
             if (k > 0 && ((bnd >> k) & 1u)) {                      /* wave-uniform branch */                                 \
               const int node = __builtin_amdgcn_readlane(i_node, k - 1);                                                     \
@@ -605,6 +615,8 @@ _Pragma("unroll")                                                               
               accv = agg_neutral;                                                                                            \
             }                                                                                                                \
             if constexpr (kAggMax) accv = __builtin_fmaxf(accv, v[kk]); else accv += v[kk];                                  \
+          }                                                                                                                  \
+            }                                                                                                                \
           }                                                                                                                  \
           __builtin_amdgcn_sched_barrier(0);                                                                                 \
         }                                                                                                                    \
@@ -1157,9 +1169,9 @@ hipError_t launch_fused_opt(A... args) {
   return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT, NOTB>(args...);
 #else
   switch (g_fused_opt) {      // (the variants without bits 6 / 11 - serial sums, scalar element-wise code - and bits 13, 16, 18 were removed in round 5)
-    case 8051 + 143360: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 4096, NOTB>(args...);    // (A/B: production + persistent workgroups)
+    case FUSED_OPT | 4096: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 4096, NOTB>(args...);    // 155507 (A/B: production + persistent workgroups)
     case 3955: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 3955, NOTB>(args...);      // (A/B: round 2's production: register gathers)
-    case 53107 + 131072: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 32768, NOTB>(args...);  // (A/B: ... + two gather units, counted waits)
+    case FUSED_OPT | 32768: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 32768, NOTB>(args...);  // 184179 (A/B: ... + two gather units, counted waits)
     case 20339: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 20339, NOTB>(args...);    // (A/B: round 3's production: no neighbour-sum fast path)
     case 150899: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 150899, NOTB>(args...);  // (A/B: production without the raised issue priority)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT, NOTB>(args...);
