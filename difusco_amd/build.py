@@ -99,7 +99,6 @@ def rocm_root() -> str:
 VARIANTS = {
     "pk_fused": (["-Xclang", "-target-feature", "-Xclang", "+packed-fp32-ops"], ("edge_layer.hip", "edge_layer_bf16.hip")),   # round 3
     "nopk_all": (NO_PK, None),
-    "opt_413555": (["-DFUSED_OPT=413555"], ("edge_layer.hip", "edge_layer_bf16.hip")),   # the fused kernel with OPT bit 18 (measured slower)
 }
 
 

@@ -2,7 +2,8 @@
 // written ONCE per layer.
 //
 //   Ce    = C e                                    gnn_encoder.py:104           GEMM 1 (matrix cores)
-//   e'    = Ah[j] + Bh[i] + (Ce + b_C)             :110
+//   e'    = Ah[j] + Bh[i] + (Ce + b_C)             :110      (carried as e' log2(e): the node rows arrive pre-multiplied with b_C
+//                                                             folded in, see "LOG2E DOMAIN" at the kernel; difusco_hip.h, ABI 11)
 //   m     = sigmoid(e') * Vh[j]  -> sum over the edges of centre node i          :112,:115,:163,:177-191
 //   y     = ReLU(LN_e(e')) (+ t_l, TSP)            :131,:135,:445
 //   a     = SiLU(LN_o(y))                          per_layer_out[l][0:2] :339-342
@@ -122,16 +123,17 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //   bit 1  the MFMAs of two weight blocks are issued alternately (two independent accumulator chains), so that no
   //          MFMA waits for the result of the one issued right before it.
   //   bit 4  non-temporal accesses for the e stream (see kNt below).
-  //   bit 5  two stages of cover for the e stream (kDeepE below);  bit 6  LayerNorm reductions as four partial sums (kPart).
+  //   bit 5  two stages of cover for the e stream (kDeepE below);  bit 6  LayerNorm reductions as four partial sums (required).
   //   bit 8  GEMM 1 input slabs of e through a buffer resource (kBufRing below).
   //   bit 9  raised issue priority outside the GEMM phases;  bit 10  default cache policy for the GEMM 1 slabs of e.
-  //   bit 11 element-wise arithmetic on register pairs (kPk below).
-  //   bit 12 persistent workgroups, bit 13 gathers two batches ahead (both measured slower, profiling library only);
+  //   bit 11 element-wise arithmetic on register pairs (required: the scalar form was removed in round 5).
+  //   bit 12 persistent workgroups (measured slower: -2.0 % round 3, -4.7 % round 5; profiling library only);
   //   bit 14 FULL-LINE neighbour-table gathers through LDS-DMA (+3.4 %, see the gather phase), bit 15 two units + counted waits (no
   //          further gain, profiling library only).
-  //   bit 17 neighbour-sum fast path for tiles with one centre node (round 4, bit-identical).
-  //   bit 18 16-bit planes of a product straight from its factors (round 4; 256 vector instructions fewer per tile and 1.2 %
-  //          SLOWER, see kMixSplit; profiling library / build variant only).
+  //   bit 17 neighbour-sum fast path for tiles with one centre node (round 4) and, on the other tiles, segment-start tests only inside
+  //          the 8-row groups that hold one (round 5); both bit-identical.
+  //   (removed in round 5, all measured slower - HISTORY.md: bit 13 gathers two batches ahead, bit 16 full-line gathers through
+  //    staging registers, bit 18 16-bit planes of a product by v_fma_mix, and the forms without bits 6 / 11)
   // Production = 151411 (bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14, 17).  Bits 0-11 = 3955: +16 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
   // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5, 8-10 do not change a result bit; bit 6
