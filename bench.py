@@ -334,7 +334,7 @@ def compact_record(out, full_path=None):
             return None
         t = r.get("traffic")
         o = {k: _r(r[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_issued", "hbm_GBs_algorithmic", "hbm_frac_of_8TBs",
-                                   "avg_launch_ms", "launches", "other_ms_per_step") if k in r}
+                                   "fabric_frac_of_8TBs", "avg_launch_ms", "launches", "other_ms_per_step") if k in r}
         o["traffic"] = None if not t else {"bytes_per_launch": _r(t["bytes_per_launch"]), "fetch_bytes": _r(t["fetch_bytes"]),
                                            "write_bytes": _r(t["write_bytes"])}
         o["kernel"] = r.get("kernel", "").split(" (")[0]

@@ -1176,6 +1176,8 @@ hipError_t launch_fused_opt(A... args) {
     case FUSED_OPT | 32768: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 32768, NOTB>(args...);  // 184179 (A/B: ... + two gather units, counted waits)
     case 20339: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 20339, NOTB>(args...);    // (A/B: round 3's production: no neighbour-sum fast path)
     case 150899: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 150899, NOTB>(args...);  // (A/B: production without the raised issue priority)
+    case 151409: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151409, NOTB>(args...);  // (A/B: production without the alternating MFMA chains, bit 1)
+    case 151379: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151379, NOTB>(args...);  // (A/B: production without the two-stage cover of the e stream, bit 5)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT, NOTB>(args...);
   }
 #endif

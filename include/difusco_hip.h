@@ -275,7 +275,9 @@ int difusco_edge_gate_aggregate(int hidden, int n_nodes, const int32_t* rowptr, 
  * difusco_amd.graph.to_tiled) - every wavefront access is then one contiguous KiB.
  * planes_c / planes_o: the five 16-bit planes of C / per_layer_out[l][2] (see *_PLANES above);
  * precision = DIFUSCO_PREC_BF16X3 | DIFUSCO_PREC_FP16X3.  scales: the layer's DIFUSCO_WL_FUSED_SCALES record (device,
- * 8 floats; required for FP16X3, ignored for BF16X3).  scratch: >= difusco_fused_scratch_bytes(). */
+ * 8 floats; required for FP16X3, ignored for BF16X3).  scratch: >= difusco_fused_scratch_bytes().
+ * node4 is the REFERENCE's U h | V h | A h | B h (gnn_encoder.py:94-103); this entry converts the A | B rows into the kernel's
+ * log2(e) domain itself (a copy in the scratch, ABI 11) - the step driver has no such pass, its node linear writes them so. */
 size_t difusco_fused_scratch_bytes(int n_nodes, int n_edges);
 int difusco_edge_layer_fused(int precision, int n_nodes, int n_edges, const int32_t* rowptr, const int32_t* row,
                              const int32_t* col, const float* node4, float* e, float* h, const void* planes_c,
