@@ -121,7 +121,9 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //          (graph.py) - the neighbour-table rows A h[j], V h[j] gathered by one XCD's workgroups are a small, spatially
   //          compact set that stays in that XCD's 4 MiB L2;
   //   bit 1  the MFMAs of two weight blocks are issued alternately (two independent accumulator chains), so that no
-  //          MFMA waits for the result of the one issued right before it.
+  //          MFMA waits for the result of the one issued right before it.  Part of the production set in rounds 2-4; OFF since
+  //          round 5: in the power-limited regime the three products of a block back to back measure 0.3-0.5 % faster on every
+  //          workload (profiles/r05/ab_mfma_chain_alternation_same_box.txt); per accumulator the order is the same: bit-identical.
   //   bit 4  non-temporal accesses for the e stream (see kNt below).
   //   bit 5  two stages of cover for the e stream (kDeepE below);  bit 6  LayerNorm reductions as four partial sums (required).
   //   bit 8  GEMM 1 input slabs of e through a buffer resource (kBufRing below).
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   //          the 8-row groups that hold one (round 5); both bit-identical.
   //   (removed in round 5, all measured slower - HISTORY.md: bit 13 gathers two batches ahead, bit 16 full-line gathers through
   //    staging registers, bit 18 16-bit planes of a product by v_fma_mix, and the forms without bits 6 / 11)
-  // Production = 151411 (bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14, 17).  Bits 0-11 = 3955: +16 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
+  // Production = 151409 (bits 0, 4, 5, 6, 8, 9, 10, 11, 14, 17).  Bits 0-11 = 3955: +16 % on the step over 0 (profiles/r02/fused_kernel_study.txt; that file also
   // records two restructurings that were measured and removed - next-stage requests issued between the MFMA groups,
   // and A h[j] + B h[i] gathered straight into the GEMM 1 accumulators).  Bits 0-5, 8-10 do not change a result bit; bit 6
   // changes the summation order of the LayerNorm statistics and bit 11 where the compiler contracts multiply-adds (fp32
@@ -1122,7 +1124,7 @@ _Pragma("unroll")                                                               
 #define FUSED_START_DELAY 0
 #endif
 #ifndef FUSED_OPT            // (-DFUSED_OPT=...: an A/B build of the production library, build.py variants)
-#define FUSED_OPT 151411     // production options (OPT bits 0, 1, 4, 5, 6, 8, 9, 10, 11, 14, 17 of the kernel)
+#define FUSED_OPT 151409     // production options (OPT bits 0, 4, 5, 6, 8, 9, 10, 11, 14, 17 of the kernel)
 #endif
 #define FUSED_OPT_R2 3955    // round 2's production set (register gathers): what the gather / neighbour-sum ablation masks are written for
 #define FUSED_NW 4          // production workgroup geometry (see fused::Geo): measured 0.97-1.00 ms vs 1.05-1.18 ms (NW = 8) per layer
@@ -1176,8 +1178,8 @@ hipError_t launch_fused_opt(A... args) {
     case FUSED_OPT | 32768: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 32768, NOTB>(args...);  // 184179 (A/B: ... + two gather units, counted waits)
     case 20339: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 20339, NOTB>(args...);    // (A/B: round 3's production: no neighbour-sum fast path)
     case 150899: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 150899, NOTB>(args...);  // (A/B: production without the raised issue priority)
-    case 151409: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151409, NOTB>(args...);  // (A/B: production without the alternating MFMA chains, bit 1)
-    case 151379: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151379, NOTB>(args...);  // (A/B: production without the two-stage cover of the e stream, bit 5)
+    case 151411: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151411, NOTB>(args...);  // (A/B: rounds 2-4's production: + alternating MFMA chains, bit 1)
+    case 151377: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151377, NOTB>(args...);  // (A/B: production without the two-stage cover of the e stream, bit 5)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT, NOTB>(args...);
   }
 #endif
