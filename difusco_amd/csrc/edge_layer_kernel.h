@@ -1013,13 +1013,17 @@ _Pragma("unroll")                                                               
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
-          FUSED_FRAG2(0, 0)
-          FUSED_FRAG2(1, 1)
+          // OPT bit 20 (experiment): block-major order inside a stage - all KPS k slabs of output block 0, then of block 1: the chain
+          // of MFMAs into one accumulator is 3 KPS = 12 long instead of 3 (per accumulator the k order is unchanged: bit-identical)
+          constexpr bool kBlockMajor = (OPT & 1048576) != 0;
+          auto frag_of = [](int bi) { return kBlockMajor ? (bi % KPS) * 2 + bi / KPS : bi; };      // fragment index ksl * 2 + nbp
+          FUSED_FRAG2(frag_of(0), 0)
+          FUSED_FRAG2(frag_of(1), 1)
 #pragma unroll
           for (int bi = 0; bi < 2 * KPS; ++bi) {
-            if (bi + 2 < 2 * KPS) FUSED_FRAG2(bi + 2, (bi + 2) % 3)
+            if (bi + 2 < 2 * KPS) FUSED_FRAG2(frag_of(bi + 2), (bi + 2) % 3)
             __builtin_amdgcn_sched_barrier(0);
-            const int ksl = bi >> 1, nbp = bi & 1;
+            const int ksl = frag_of(bi) >> 1, nbp = frag_of(bi) & 1;
             const int sl = KPS * kc + ksl;        // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
             acc2[nbp] = T::mfma(fl[bi % 3], ah_[sl >> 1][sl & 1], acc2[nbp]);
             acc2[nbp] = T::mfma(fh[bi % 3], al_[sl >> 1][sl & 1], acc2[nbp]);
@@ -1180,6 +1184,7 @@ hipError_t launch_fused_opt(A... args) {
     case 150899: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 150899, NOTB>(args...);  // (A/B: production without the raised issue priority)
     case 151411: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151411, NOTB>(args...);  // (A/B: rounds 2-4's production: + alternating MFMA chains, bit 1)
     case 151377: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151377, NOTB>(args...);  // (A/B: production without the two-stage cover of the e stream, bit 5)
+    case FUSED_OPT | 1048576: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 1048576, NOTB>(args...);  // 1199985 (A/B: GEMM 2 block-major inside a stage)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT, NOTB>(args...);
   }
 #endif
