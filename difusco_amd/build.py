@@ -99,6 +99,10 @@ def rocm_root() -> str:
 VARIANTS = {
     "pk_fused": (["-Xclang", "-target-feature", "-Xclang", "+packed-fp32-ops"], ("edge_layer.hip", "edge_layer_bf16.hip")),   # round 3
     "nopk_all": (NO_PK, None),
+    # the fused translation units under LLVM's other instruction-scheduling strategies (round 5 A/B; all compile without scratch)
+    "sched_maxilp": (["-mllvm", "-amdgpu-sched-strategy=max-ilp"], ("edge_layer.hip", "edge_layer_bf16.hip")),
+    "sched_memclause": (["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"], ("edge_layer.hip", "edge_layer_bf16.hip")),
+    "sched_iterilp": (["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"], ("edge_layer.hip", "edge_layer_bf16.hip")),
 }
 
 
@@ -125,6 +129,9 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False, varian
         def compile_one(src):
             obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
             extra = EXTRA_FLAGS.get(src, []) + (var_flags if (var_sources is None or src in var_sources) else [])
+            if sum(f.startswith("-amdgpu-sched-strategy=") for f in extra) > 1:      # a variant's strategy replaces the default one
+                first = next(i for i, f in enumerate(extra) if f.startswith("-amdgpu-sched-strategy="))
+                extra = extra[:first - 1] + extra[first + 1:]
             if src == "stage_lab.hip@nopk":      # the stage-loop laboratory a second time, without packed fp32 arithmetic
                 src, extra = "stage_lab.hip", extra + NO_PK + ["-DDIFUSCO_LAB_NOPK=1"]
                 obj = os.path.join(tmp, "stage_lab_nopk.o")

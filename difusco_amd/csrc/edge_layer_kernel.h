@@ -428,6 +428,9 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
   // stage then ends with vmcnt(2) instead of vmcnt(0): the weight pieces have landed (requests complete in order), the
   // e loads stay in flight across the barrier and are waited for at the end of the NEXT stage.
   constexpr bool kDeepE = (OPT & 32) != 0;
+  // OPT bit 21 (experiment): no scheduling fences around the MFMA triples of the GEMM loops - the compiler places the fragment reads and
+  // the operand splits between the MFMAs as its scheduler sees fit
+  constexpr bool kFreeSched = (OPT & 2097152) != 0;
   static_assert(!kDeepE || (SPS == 1 && RING == 2), "OPT bit 5 is written for the 16 KiB stages");
 #pragma unroll
   for (int t = 0; t < (L0 ? 0 : NS1); ++t) {
@@ -497,12 +500,12 @@ __global__ __launch_bounds__(64 * fused::geo_waves(NW), 2) void edge_layer_fused
 #pragma unroll
       for (int bi = 0; bi < 8 * SPS; ++bi) {
         if (bi + 2 < 8 * SPS) FUSED_FRAG1(bi + 2, (bi + 2) % 3)
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!kFreeSched) __builtin_amdgcn_sched_barrier(0);
         const int nb = bi & 7, sub = bi >> 3;
         acc1[nb] = T::mfma(fl[bi % 3], xh[sub], acc1[nb]);
         acc1[nb] = T::mfma(fh[bi % 3], xl[sub], acc1[nb]);
         acc1[nb] = T::mfma(fh[bi % 3], xh[sub], acc1[nb]);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!kFreeSched) __builtin_amdgcn_sched_barrier(0);
       }
     }
 #undef FUSED_FRAG1
@@ -1022,13 +1025,13 @@ _Pragma("unroll")                                                               
 #pragma unroll
           for (int bi = 0; bi < 2 * KPS; ++bi) {
             if (bi + 2 < 2 * KPS) FUSED_FRAG2(frag_of(bi + 2), (bi + 2) % 3)
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!kFreeSched) __builtin_amdgcn_sched_barrier(0);
             const int ksl = frag_of(bi) >> 1, nbp = frag_of(bi) & 1;
             const int sl = KPS * kc + ksl;        // slab of W_o = features 16 sl .. 16 sl + 15 of the activation
             acc2[nbp] = T::mfma(fl[bi % 3], ah_[sl >> 1][sl & 1], acc2[nbp]);
             acc2[nbp] = T::mfma(fh[bi % 3], al_[sl >> 1][sl & 1], acc2[nbp]);
             acc2[nbp] = T::mfma(fh[bi % 3], ah_[sl >> 1][sl & 1], acc2[nbp]);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!kFreeSched) __builtin_amdgcn_sched_barrier(0);
           }
         }
 #undef FUSED_FRAG2
@@ -1184,6 +1187,7 @@ hipError_t launch_fused_opt(A... args) {
     case 150899: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 150899, NOTB>(args...);  // (A/B: production without the raised issue priority)
     case 151411: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151411, NOTB>(args...);  // (A/B: rounds 2-4's production: + alternating MFMA chains, bit 1)
     case 151377: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, 151377, NOTB>(args...);  // (A/B: production without the two-stage cover of the e stream, bit 5)
+    case FUSED_OPT | 2097152: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 2097152, NOTB>(args...);  // 2248561 (A/B: no scheduling fences around the MFMA triples)
     case FUSED_OPT | 1048576: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT | 1048576, NOTB>(args...);  // 1199985 (A/B: GEMM 2 block-major inside a stage)
     default: return launch_fused_t<T, 0, FUSED_NW, L0, GNP, TAIL, FUSED_OPT, NOTB>(args...);
   }
