@@ -684,3 +684,27 @@ def test_node4_fused_vectors():
     base = len(_lib.W_GLOBAL) + 1 * len(_lib.W_LAYER)
     ib, isc = base + _lib.W_LAYER.index("@node4.fused_bias"), base + _lib.W_LAYER.index("@node4.fused_scale")
     assert torch.equal(blob[off[ib]: off[ib] + 4 * H], bias) and torch.equal(blob[off[isc]: off[isc] + 8 * H], scale)
+
+
+def test_bench_power_sampler_reads_hwmon_files(tmp_path):
+    """bench.py's live power / clock sampler: hwmon-style files (microwatts, hertz) read by a background thread between start() and
+    stop(); the summary carries medians and joules per graph-step; with no readable source it reports zero samples instead of failing."""
+    import importlib.util
+    import time
+    root = os.path.dirname(os.path.dirname(__file__))
+    spec = importlib.util.spec_from_file_location("bench_module3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    s = bench.PowerSampler(torch.device("cpu"), period=0.002)
+    (tmp_path / "power1_input").write_text("1300000000\n")
+    (tmp_path / "freq1_input").write_text("1850000000\n")
+    s.power_file, s.freq_file, s.source = str(tmp_path / "power1_input"), str(tmp_path / "freq1_input"), "hwmon power1_input + freq1_input"
+    s.start()
+    time.sleep(0.05)
+    s.stop()
+    out = s.summary(seconds_per_step=9.0e-3, graphs=8)
+    assert out["samples"] >= 5 and out["power_W_median"] == 1300.0 and out["sclk_MHz_median"] == 1850.0
+    assert abs(out["J_per_graph_step"] - 1300.0 * 9.0e-3 / 8) < 1e-9
+    empty = bench.PowerSampler(torch.device("cpu"))
+    empty.power_file, empty.samples = None, [(None, None)]
+    assert empty.summary(1.0, 1)["samples"] == 0
