@@ -138,10 +138,15 @@ __global__ __launch_bounds__(256, 2) void linear_rows_split_kernel(const float* 
       gr = gr < M ? gr : M - 1;                                                                       \
       if constexpr (GEN) {                                                                            \
         const float xv = X[gen_perm ? gen_perm[gr] : gr];                                             \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
-          const int c = (KT) + c4 * 4 + q;                                                            \
+        /* features 2j, 2j + 1 are sin, cos of the SAME angle (dim_t[2j] == dim_t[2j + 1], gnn_encoder.py:242-247): one */ \
+        /* precise sincosf - one argument reduction - per pair instead of a sinf and a cosf (round 5) */       \
+        _Pragma("unroll") for (int q2 = 0; q2 < 2; ++q2) {                                            \
+          const int c = (KT) + c4 * 4 + 2 * q2;                                                       \
           const float v = xv / gen_dimt[c];                                                           \
-          xr_[SLOT][i][q] = (c & 1) ? cosf(v) : sinf(v);                                                     \
+          float sn, cs;                                                                               \
+          sincosf(v, &sn, &cs);                                                                       \
+          xr_[SLOT][i][2 * q2] = sn;                                                                  \
+          xr_[SLOT][i][2 * q2 + 1] = cs;                                                              \
         }                                                                                             \
       } else {                                                                                        \
         xr_[SLOT][i] = *reinterpret_cast<const v4f*>(X + gr * K + (KT) + c4 * 4);                            \
