@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdifusco_hip.so")
 PROF_LIB_PATH = os.path.join(LIB_DIR, "libdifusco_hip_prof.so")
-SOURCES = ["linear.hip", "linear_split.hip", "node_linear.hip", "edge_layer.hip", "edge_layer_bf16.hip", "graph_kernels.hip", "decode.hip", "two_opt.hip", "knn.hip", "mis_decode.hip", "formats.hip", "api.hip"]
+SOURCES = ["linear.hip", "linear_split.hip", "node_linear.hip", "edge_embed.hip", "edge_layer.hip", "edge_layer_bf16.hip", "graph_kernels.hip", "decode.hip", "two_opt.hip", "knn.hip", "mis_decode.hip", "formats.hip", "api.hip"]
 PROF_SOURCES = SOURCES + ["edge_layer_abl.hip", "stage_lab.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "edge_layer_common.h"), os.path.join(CSRC, "edge_layer_kernel.h"),
            os.path.join(os.path.dirname(PKG), "include", "difusco_hip.h")]

@@ -389,10 +389,9 @@ int difusco_denoise_step(const difusco_step_args* a) {
       if (fused) {   // sinusoidal features generated inside the linear: the E x H embedding never exists in memory
         const unsigned short* pl = reinterpret_cast<const unsigned short*>(G(DIFUSCO_W_EDGE_EMBED_PLANES)) +
                                    (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0);
-        PROF(PROF_EMBED, linear_scalar_embed_split(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), pl, (long long)H * H,
-                                                   a->precision, G(DIFUSCO_W_EDGE_EMBED_B), ws.e, E, st, /*tiled_out=*/1,
-                                                   G(DIFUSCO_W_EDGE_EMBED_PLANES) + (long long)5 * H * H / 2,
-                                                   f16 ? ws.etmax : nullptr))
+        PROF(PROF_EMBED, launch_edge_embed_tiled(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), pl, (long long)H * H, a->precision,
+                                                 f16 ? G(DIFUSCO_W_EDGE_EMBED_PLANES) + (long long)5 * H * H / 2 : nullptr,
+                                                 G(DIFUSCO_W_EDGE_EMBED_B), ws.e, E, f16 ? ws.etmax : nullptr, st))
       } else {
         PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
         PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_PLANES),

@@ -1,0 +1,171 @@
+// Edge embedding of a step whose edge input is NOT a two-row table (Gaussian diffusion; categorical x_t that is not exactly {0,1}):
+//   e0[s] = edge_embed( ScalarEmbeddingSine(x_t[s]) )        gnn_encoder.py:230-249 (features), :304,:395 (the linear)
+// for gfx950, H = 256, written straight into the TILED edge state the fused layers read (kernels.h: edge_tiled_offset) together with
+// the per-tile max |e| that scales the next kernel's fp16 operand.
+//
+// Same dataflow as GEMM 1 of the fused edge kernel (edge_layer_kernel.h): D[f][edge] = sum_k W[f][k] X[edge][k] with the weight planes
+// as the A operand, streamed through LDS in 16 KiB stages ([256 rows][16 k] x 2 planes, double buffered, LDS-DMA, XOR-swizzled rows,
+// one barrier per stage), and the 32 edges of a wave as the B operand - here GENERATED: the sixteen k values a lane contributes to
+// slab t are four (sin, cos) pairs of x / dim_t, one precise sincosf each, computed between the request of stage t + 1 and the MFMAs of
+// stage t (the vector work covers the DMA latency).  A lane ends with the 128 features {32 nb + 8 g + 4 hh + 0..3} of ITS edge: float4
+// stores of whole KiB per wave instruction, no LDS round trip.
+// The general row-linear with generated rows (linear_split.hip, GEN) stages both operands through LDS with two barriers per 16-k step:
+// 0.78 ms per launch at E = 10^6; this kernel is what the step driver uses on the fused path (round 5), the general one stays for
+// the unfused sequence.  Arithmetic of the features: that of scalar_embed_kernel / the GEN path (x / dim_t[c], precise sincosf).
+#include "edge_layer_common.h"
+
+namespace difusco {
+
+namespace edge_embed {
+constexpr int H = 256, WAVES = 4, NS = 16;      // 16 stages = 16 k slabs
+constexpr int PLANE = 256 * 16;                 // 16-bit elements of one plane of one stage
+constexpr int BUF = 2 * PLANE;                  // one stage: 2 planes (16 KiB)
+}  // namespace edge_embed
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void edge_embed_tiled_kernel(const float* __restrict__ x, const int* __restrict__ perm,
+                                                                  const float* __restrict__ dimt,
+                                                                  const unsigned short* __restrict__ planes, long long plane_stride,
+                                                                  const float* __restrict__ w_inv, const float* __restrict__ bias,
+                                                                  float* __restrict__ e, long long n_edges,
+                                                                  float* __restrict__ tile_max) {
+  using namespace edge_embed;
+  typedef typename T::frag frag;
+  // (ONE __shared__ object: the two stage buffers and, behind them, the 256 dim_t values.  dim_t is read from LDS, not from global
+  //  memory: a global load issued after a stage request sits behind the LDS-DMA pieces in the in-order vmcnt queue, so waiting for
+  //  it would wait for the stage - the double buffering would be gone)
+  __shared__ __attribute__((aligned(16))) unsigned short wbuf[2 * BUF + 2 * H];      // 32 KiB + 1 KiB
+  float* const dimt_s = reinterpret_cast<float*>(wbuf + 2 * BUF);
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long tile = (long long)blockIdx.x * WAVES + wave;
+  const long long s_raw = tile * 32 + l31;
+  const bool valid = s_raw < n_edges;
+  const long long s = valid ? s_raw : n_edges - 1;      // lanes past the end redo the last edge and store nothing
+
+  // ---- weight stages by LDS-DMA (the fused kernel's scheme for GEMM 1: wave w moves pieces 2 w, 2 w + 1 of the eight 1-KiB pieces of
+  // a plane; lane L fills slot (piece, L) = entry piece * 32 + L / 2, and fetches the half that belongs there - wslot's XOR on the source)
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(planes), 0, 0x7fffffff, 0x00020000);
+  const int plane_bytes = (int)plane_stride * 2;
+  unsigned dvoff;
+  {
+    const int entry0 = (2 * wave) * 32 + (lane >> 1), half = (lane & 1) ^ ((lane >> 4) & 1);
+    dvoff = (unsigned)(entry0 * 16 + half * 8) * 2;      // bytes inside the stage's [256 rows][16 k] slab
+  }
+#define EMBED_DMA_STAGE(t)                                                                                          \
+  {                                                                                                                 \
+    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl)                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w,                                                                \
+          (__attribute__((address_space(3))) void*)(wbuf + ((t) & 1) * BUF + pl * PLANE + (2 * wave + i) * 512), 16, \
+          dvoff, (t) * 8192 + pl * plane_bytes + i * 1024, 0, 0);                                                    \
+  }
+  const float xv = x[perm ? perm[s] : s];
+  dimt_s[tid] = dimt[tid];      // (256 threads, 256 features; visible after the barrier below)
+  EMBED_DMA_STAGE(0)
+
+  constexpr float kXScale = T::kScaled ? 16384.0f : 1.0f;      // |sin|, |cos| <= 1: the fp16 planes are those of the features x 2^14
+  v16f acc[8];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's pieces of stage 0
+  __syncthreads();
+  const int a_off = wslot(l31, hh);
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    if (t + 1 < NS) {      // into the other buffer: every wave left it at the last barrier
+      EMBED_DMA_STAGE(t + 1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // B operand of slab t: features 16 t + {4 hh .. 4 hh + 3} and 16 t + 8 + {4 hh .. 4 hh + 3} of this lane's edge = four (sin, cos)
+    // pairs (features 2 j, 2 j + 1 share dim_t)
+    frag xh, xl;
+    {
+      float xs[8];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int c = 16 * t + 8 * (p >> 1) + 4 * hh + 2 * (p & 1);
+        const float v = xv / dimt_s[c];
+        float sn, cs;
+        sincosf(v, &sn, &cs);
+        xs[2 * p] = sn * kXScale;
+        xs[2 * p + 1] = cs * kXScale;
+      }
+      split8<T>(xs, xh, xl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned short* wb = wbuf + (t & 1) * BUF + a_off;
+    frag fh[3], fl[3];
+#define EMBED_FRAG(bi, slot)                                                       \
+  {                                                                                \
+    fh[slot] = *reinterpret_cast<const frag*>(wb + (bi) * 32 * 16);                \
+    fl[slot] = *reinterpret_cast<const frag*>(wb + PLANE + (bi) * 32 * 16);        \
+  }
+    EMBED_FRAG(0, 0)
+    EMBED_FRAG(1, 1)
+#pragma unroll
+    for (int bi = 0; bi < 8; ++bi) {
+      if (bi + 2 < 8) EMBED_FRAG(bi + 2, (bi + 2) % 3)
+      __builtin_amdgcn_sched_barrier(0);
+      acc[bi] = T::mfma(fl[bi % 3], xh, acc[bi]);      // smallest terms first
+      acc[bi] = T::mfma(fh[bi % 3], xl, acc[bi]);
+      acc[bi] = T::mfma(fh[bi % 3], xh, acc[bi]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef EMBED_FRAG
+    if (t + 1 < NS) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): stage t + 1 has landed (this wave's pieces)
+      __syncthreads();
+    }
+  }
+#undef EMBED_DMA_STAGE
+
+  // ---- epilogue: undo the operand scales, add the bias, store the tile, leave its max |e| for the next kernel -------------------
+  float* const etile = e + tile * (32 * H);
+  constexpr float kInvX = T::kScaled ? 1.0f / 16384.0f : 1.0f;
+  float tmx = 0.0f;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f = 32 * nb + 8 * g + 4 * hh;
+      const v4f b = *reinterpret_cast<const v4f*>(bias + f);
+      v4f sc = {kInvX, kInvX, kInvX, kInvX};
+      if (w_inv != nullptr) sc = *reinterpret_cast<const v4f*>(w_inv + f) * kInvX;      // (powers of two: exact)
+      v4f v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = acc[nb][4 * g + q] * sc[q] + b[q];
+      if (valid) {
+        *reinterpret_cast<v4f*>(etile + (2 * nb + (g >> 1)) * 512 + (g & 1) * 256 + lane * 4) = v;
+        tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+        tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+      }
+    }
+  if (tile_max != nullptr) {      // (pad lanes contribute 0; a tile entirely past the end - the padding of the last workgroup - reports 0)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tmx = __builtin_fmaxf(tmx, __shfl_xor(tmx, off, 64));
+    if (lane == 0) tile_max[tile] = tmx;
+  }
+}
+
+// mode: 1 = bf16 planes (unscaled), 3 = fp16 planes (w_inv required).  planes: first plane of that type, [16 slabs][256 rows][16];
+// e: tiled [ceil(n_edges / 256) * 256, 256]; tile_max: one float per 32-edge tile of the padded range, or null.
+hipError_t launch_edge_embed_tiled(const float* x, const int* perm, const float* dimt, const unsigned short* planes, long long plane_stride,
+                                   int mode, const float* w_inv, const float* bias, float* e, long long n_edges, float* tile_max,
+                                   hipStream_t stream) {
+  if (n_edges <= 0) return hipSuccess;
+  if ((mode != 1 && mode != 3) || (mode == 3 && w_inv == nullptr)) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)((n_edges + 127) / 128);
+  if (mode == 3)
+    hipLaunchKernelGGL((edge_embed_tiled_kernel<FFp16>), dim3(grid), dim3(256), 0, stream, x, perm, dimt, planes, plane_stride, w_inv, bias, e,
+                       n_edges, tile_max);
+  else
+    hipLaunchKernelGGL((edge_embed_tiled_kernel<FBf16>), dim3(grid), dim3(256), 0, stream, x, perm, dimt, planes, plane_stride, nullptr, bias, e,
+                       n_edges, tile_max);
+  return hipGetLastError();
+}
+
+}  // namespace difusco

@@ -61,6 +61,12 @@ hipError_t linear_scalar_embed_split(const float* x, const int* perm, const floa
                                      long long plane_stride, int mode, const float* bias, float* y, long long m,
                                      hipStream_t stream, int tiled_out, const float* w_inv, float* tile_max);
 
+// the same product for the FUSED path (edge_embed.hip): e0 written in the tiled edge layout with its per-tile max |e|; the dataflow of
+// the fused edge kernel's GEMM 1 (weights streamed through LDS by LDS-DMA, the generated rows as the register-resident MFMA operand)
+hipError_t launch_edge_embed_tiled(const float* x, const int* perm, const float* dimt, const unsigned short* planes, long long plane_stride,
+                                   int mode, const float* w_inv, const float* bias, float* e, long long n_edges, float* tile_max,
+                                   hipStream_t stream);
+
 // scale[r] = power-of-two operand scale of row r of x[m][k] (fp16 split path)
 hipError_t launch_row_pow2_scale(const float* x, long long m, int k, float* scale, hipStream_t stream);
 // *count += number of inf / nan values in x[0..n)  (DIFUSCO_FLAG_CHECK_FINITE)
