@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round 5, GPU call O: the FINAL tree (with edge_embed.hip) - whole GPU suite, smoke, the driver's bench command.
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+OUT=gpurun_out/r05o
+mkdir -p $OUT
+timeout 700 python -m pytest tests -x -q -m gpu > $OUT/test_gpu_all.txt 2>&1; echo "gpu suite exit $?"; tail -3 $OUT/test_gpu_all.txt
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke exit $?"; tail -1 $OUT/smoke.txt
+BENCH_FULL_JSON=$OUT/bench_driver_cmd_full.json timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err; echo "bench exit $?"
+python - <<'PY'
+import json
+lines = open("gpurun_out/r05o/bench_driver_cmd.json").read().strip().splitlines()
+o = json.loads(lines[-1])
+print("stdout lines", len(lines), "bytes", len(lines[-1]), "value", round(o["value"], 1), "rep", o["repeats"]["ms_per_step"], "fused", o["roofline"]["avg_launch_ms"],
+      "other", o["roofline"]["other_ms_per_step"], "power", o.get("power", {}).get("power_W_median"), "cpu", o["cpu_baseline"]["value"], "parity", o["parity_linf"])
+for k, w in o["workloads"].items():
+    print("  ", k, w["value"], w["rep_ms"], w["parity_linf"], w["other_ms"])
+PY
