@@ -139,17 +139,20 @@ def pack_state_dict(state) -> torch.Tensor:
         put(i, fetch(name))
     for l in range(n_layers):
         base = len(_lib.W_GLOBAL) + l * len(_lib.W_LAYER)
+        node4_planes = None      # split planes of this layer's [4H, H] node linear: needed by three entries, computed once
         for i, name in enumerate(_lib.W_LAYER):
+            if name in ("@planes:@node4.weight", "@node4.fused_bias", "@node4.fused_scale") and node4_planes is None:
+                node4_planes = split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0), per_row=True)
             if name == "@node4.weight":      # rows U | V | A | B  -> one [4H, H] linear on node rows
                 t = torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0)
             elif name == "@node4.bias":
                 t = torch.cat([state[f"layers.{l}.{m}.bias"] for m in "UVAB"], dim=0)
             elif name == "@planes:@node4.weight":
-                t = split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0), per_row=True)
+                t = node4_planes
             elif name == "@node4.fused_bias":
-                t = node4_fused_vectors(state, l, hidden, split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0), per_row=True))[0]
+                t = node4_fused_vectors(state, l, hidden, node4_planes)[0]
             elif name == "@node4.fused_scale":
-                t = node4_fused_vectors(state, l, hidden, split_planes(torch.cat([state[f"layers.{l}.{m}.weight"] for m in "UVAB"], dim=0), per_row=True))[1]
+                t = node4_fused_vectors(state, l, hidden, node4_planes)[1]
             elif name == "@fused_scales":
                 t = fused_scales(state[f"layers.{l}.C.weight"], state[f"per_layer_out.{l}.2.weight"],
                                  state[f"per_layer_out.{l}.0.weight"], state[f"per_layer_out.{l}.0.bias"])
