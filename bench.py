@@ -2,8 +2,14 @@
 """bench.py - denoising-step throughput of the MI355X-native DIFUSCO sampler.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: bench.py starts its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Both N > 1 forms run the same code: one process per GPU (the reference's deployment, difusco/train.py:106-115; independent
+graph instances per rank, pl_tsp_model.py:254-255), RCCL for the one weight broadcast.  A command whose --gpus does not match
+the ranks that actually run (WORLD_SIZE from a launcher, the visible devices, the ranks RCCL gathered) exits non-zero: a
+`--gpus 8` command never prints an `n_gpus: 1` line.
 
 Metric (BASELINE.json): graph-steps/s = graphs in flight x denoise steps / wall time, on the headline
 configuration TSP-1000 k-NN-sparse (K=100), categorical diffusion, H=256, 12 layers, fp32,
@@ -198,6 +204,25 @@ class PowerSampler:
                 "J_per_graph_step": med * seconds_per_step / max(graphs, 1), "source": self.source + ", sampled inside the timed loops"}
 
 
+def smu_sampler(device):
+    """The firmware's own account of what holds the engine clock (scripts/smu_metrics.py: gpu_metrics v1.8 through libamd_smi):
+    throttler residency shares (PPT / thermal / VR / HBM / PROCHOT) and, per XCD, the share of the timed loops the engine clock
+    sat below the host limit because of power or temperature.  None when the metrics table cannot be read on this box."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from smu_metrics import SmuMetrics, SmuSampler
+        pr = torch.cuda.get_device_properties(device)
+        m = SmuMetrics(pci_bdf=f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0",
+                       index=device.index or 0)
+        if not m.available:
+            log(f"[bench] SMU metrics not available: {m.why}")
+            return None
+        return SmuSampler(m, period=0.02)
+    except Exception as exc:      # noqa: BLE001
+        log(f"[bench] SMU metrics not available: {exc}")
+        return None
+
+
 def oracle_threads():
     """torch threads for the CPU-oracle leg.  Measured on the GPU box's host (2 x EPYC 9575F, 128 physical cores,
     profiles/r02/cpu_threads_scan.txt, one TSP-1000 step): 16 threads 4.8 s, 32 threads 4.2 s, 64 threads 5.7 s,
@@ -347,7 +372,15 @@ def compact_record(out, full_path=None):
                                                        "parity_bits_equal", "parity_xt_linf") if k in cb}
         keep["cpu_baseline"]["sample"] = cb.get("sample_short", "")
     if "power" in out:
-        keep["power"] = _r(out["power"])
+        pw = dict(out["power"])
+        thr = pw.pop("throttle", None)
+        keep["power"] = {k: _r(v) for k, v in pw.items() if k != "source"}
+        if thr and thr.get("residency"):      # shares of the timed loops (firmware accumulators): which limiter held the clock
+            rs = thr["residency"]
+            keep["power"]["throttle"] = {k: _r(rs.get(k), 3) for k in ("ppt", "socket_thm", "vr_thm", "hbm_thm", "prochot",
+                                                                        "gfx_below_host_limit_ppt", "gfx_below_host_limit_thm",
+                                                                        "gfx_below_host_limit_total") if rs.get(k) is not None}
+            keep["power"]["throttle"].update({"gfxclk_MHz": thr.get("gfxclk_MHz_median"), "hotspot_C": thr.get("temp_hotspot_C_max")})
     if "exact_fp32" in out:
         keep["exact_fp32"] = {"value": _r(out["exact_fp32"]["value"]), "ms_per_step": _r(out["exact_fp32"]["ms_per_step"])}
     if "workloads" in out:
@@ -366,14 +399,35 @@ def compact_record(out, full_path=None):
 # BASELINE.json configs[1..4].  tsp1000 is the configuration the metric is quoted on (the default; it fits one GPU
 # at 8 graphs per GPU); the others are the remaining single-GPU shards of the reference's configurations.
 WORKLOADS = {
-    "tsp1000": dict(task="tsp", diffusion="categorical", nodes=1000, knn=100, graphs_per_gpu=8),
-    "tsp500": dict(task="tsp", diffusion="categorical", nodes=500, knn=50, graphs_per_gpu=16),
-    "tsp10000": dict(task="tsp", diffusion="gaussian", nodes=10000, knn=100, graphs_per_gpu=1),
-    "mis": dict(task="mis", diffusion="categorical", nodes=None, knn=None, graphs_per_gpu=16),
+    # `global_batch` = the literal batch of the BASELINE config (--scaling strong splits IT over the N ranks); `graphs_per_gpu` =
+    # its per-GPU share on the 8-GPU node the config names (--scaling weak, the default: fixed per-GPU work)
+    "tsp1000": dict(task="tsp", diffusion="categorical", nodes=1000, knn=100, graphs_per_gpu=8, global_batch=64),
+    "tsp500": dict(task="tsp", diffusion="categorical", nodes=500, knn=50, graphs_per_gpu=16, global_batch=16),
+    "tsp10000": dict(task="tsp", diffusion="gaussian", nodes=10000, knn=100, graphs_per_gpu=1, global_batch=8),
+    "mis": dict(task="mis", diffusion="categorical", nodes=None, knn=None, graphs_per_gpu=16, global_batch=128),
     # BASELINE configs[0]'s model (dense TSP-50, no k-NN sparsification) with 16 parallel samples in one call: per-sample GroupNorm
     # statistics (gnn_encoder.py:380), complete-graph CSR, fused layers since round 4
-    "tsp50dense": dict(task="tsp", diffusion="categorical", nodes=50, knn=None, graphs_per_gpu=16, dense=True),
+    "tsp50dense": dict(task="tsp", diffusion="categorical", nodes=50, knn=None, graphs_per_gpu=16, global_batch=16, dense=True),
 }
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-run this command under `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` - one process per GPU, LOCAL_RANK = device - and
+    return its exit code.  stdout is inherited: rank 0's compact line is the only thing on it."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -427,24 +481,39 @@ def main():
     ap.add_argument("--no-prepare", action="store_true", help="A/B: recompute the step-invariant part of a TSP step (node "
                     "embedding, layer-0 node linear, time-bias rows) in every step instead of once per (graph, schedule)")
     ap.add_argument("--no-power", action="store_true", help="do not sample socket power / engine clock during the timed loops")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank steps `graphs_per_gpu` graphs, the global batch grows with N; strong: the "
+                         "BASELINE config's literal global batch (64 x TSP-1000, --global-batch to override) is split over the N ranks")
+    ap.add_argument("--global-batch", type=int, default=None, help="--scaling strong: override the workload's global batch")
     ap.add_argument("--sub-steps", type=int, default=10, help="timed steps of each `workloads` entry (4 warm-up steps; three repetitions)")
     args = ap.parse_args()
     if args.aggregation != "sum":      # an A/B of the kernels only: the oracle legs and the sub-records are written for the metric (sum)
         args.cpu_steps, args.no_exact_fp32, args.no_workloads = 0, True, True
 
+    # Test hook (tests/test_dist_cpu.py): BENCH_PLUMBING_DRY_RUN=1 walks the multi-rank plumbing of this file on CPU tensors
+    # over gloo - the self-launch, rendezvous, rank-0 packing + blob broadcast, graph sharding, the optional statistics
+    # all-reduce, the barriers and the max-over-ranks timing - with the denoise step replaced by a stand-in that runs NO
+    # kernel.  Its JSON line is marked "dry_run" and is not a measurement.
+    dry = os.environ.get("BENCH_PLUMBING_DRY_RUN") == "1"
+    single_device = os.environ.get("BENCH_SINGLE_DEVICE") == "1"      # test hook: several ranks on one GPU (with BENCH_BACKEND=gloo)
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback path)")
+    if args.gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} is not a rank count")
+    if not dry and not single_device and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) are visible: refusing to "
+                         f"run fewer ranks than asked for")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the N ranks ourselves (the same `torch.distributed.run` command the driver uses) and hand back
+        # its exit code; rank 0 of that job prints the one line
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
-    # Test hook (tests/test_dist_cpu.py): BENCH_PLUMBING_DRY_RUN=1 walks the multi-rank plumbing of this file on CPU tensors
-    # over gloo - rendezvous, rank-0 packing + blob broadcast, graph sharding, the optional statistics all-reduce, the
-    # barriers and the max-over-ranks timing - with the denoise step replaced by a stand-in that runs NO kernel.  Its JSON
-    # line is marked "dry_run" and is not a measurement.
-    dry = os.environ.get("BENCH_PLUMBING_DRY_RUN") == "1"
-    if not dry and not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback path)")
-    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":     # test hook: several ranks on one GPU (with BENCH_BACKEND=gloo)
+        raise SystemExit(f"bench.py: the launcher started WORLD_SIZE={world} ranks but the command says --gpus {args.gpus}: refusing "
+                         f"to print a line whose n_gpus differs from the command")
+    if single_device:
         local_rank = 0
     if dry:
         device = torch.device("cpu")
@@ -493,7 +562,7 @@ def main():
                 out["workloads"][name] = keep
         # The FULL record (every sub-record, the prose fields, per-level traffic) goes to a file and to stderr; the LAST - and
         # only - stdout line is a compact record (< 4 KB) with the contract's fields, so that a log tail always holds all of it.
-        full_path = os.environ.get("BENCH_FULL_JSON", os.path.join(ROOT, "bench_full.json"))
+        full_path = os.environ.get("BENCH_FULL_JSON", os.path.join(ROOT, "bench_full.json"))      # (git-ignored, never tracked)
         try:
             with open(full_path, "w") as fh:
                 json.dump(out, fh)
@@ -503,11 +572,18 @@ def main():
         log("[bench] full record: " + json.dumps(out))
         rec = compact_record(out, full_path)
         line = json.dumps(rec, separators=(",", ":"))
-        for drop in ("host_enqueue_us_per_step", "prepare_ms_per_sampling_run", "exact_fp32", "power", "workloads"):
+        for drop in ("host_enqueue_us_per_step", "prepare_ms_per_sampling_run", "exact_fp32", "workloads", "power", "repeats",
+                     "rank_ms_per_step"):
             if len(line) < 4096:      # (never lose the line to its own size: shed the optional fields first - they stay in the full record)
                 break
             log(f"[bench] compact line is {len(line)} bytes: dropping `{drop}` from it")
             rec.pop(drop, None)
+            line = json.dumps(rec, separators=(",", ":"))
+        if len(line) >= 4096:      # still too long (a very long workload description): the contract's fields only
+            log(f"[bench] ERROR: compact line is still {len(line)} bytes after shedding every optional field; printing the contract's fields only")
+            rec = {k: rec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                       "scaling", "vs_baseline", "dtype", "data", "roofline", "cpu_baseline", "full_record") if k in rec}
+            rec["config"] = {"workload": str(out.get("config", {}).get("workload", ""))[:200]}
             line = json.dumps(rec, separators=(",", ":"))
         print(line, flush=True)
     if world > 1:
@@ -573,9 +649,18 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         model = (MISModel if mis else TSPModel)(margs, engine=engine, seed=1234 + rank, gn_reduce=gn_reduce,
                                                 reorder_nodes=not args.no_node_reorder, prepare=not args.no_prepare)
 
-    # this rank's shard of the global batch (weak scaling: graphs_per_gpu fixed)
-    G_total = graphs_per_gpu * world
+    # this rank's shard of the global batch.  weak: graphs_per_gpu fixed, the global batch grows with N; strong (headline run
+    # only): the config's literal global batch split over the ranks (shard_range: sizes differ by at most one graph)
+    strong = args.scaling == "strong" and overrides
+    if strong:
+        G_total = int(args.global_batch or wl["global_batch"])
+        if G_total < world:
+            raise SystemExit(f"bench.py: --scaling strong: global batch {G_total} < {world} ranks")
+    else:
+        G_total = graphs_per_gpu * world
     lo, hi = shard_range(G_total, rank, world)
+    if strong:
+        graphs_per_gpu = hi - lo      # (rank 0's share: what `config.graphs_per_gpu` reports)
     gen = torch.Generator().manual_seed(77 + rank)
     if mis:
         # Erdos-Renyi G(n, 0.15), n ~ U{700..800} per graph (data/README.md:60-68), + reversed copies + self loops
@@ -674,12 +759,15 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
     repeats = max(1, args.repeats)
     rep_dt, rep_enq, rep_local, rep_prof = [], [], [], []
     sampler = PowerSampler(device) if (rank == 0 and not dry and not args.no_power) else None
+    smu = smu_sampler(device) if sampler is not None else None      # the firmware's throttler residency counters (power.throttle)
     for rep in range(repeats):      # every repetition: exactly `steps` steps between two fences, max over ranks
         if not args.no_profile:     # (re-arms the HIP-event brackets: the events exist after the first call, nothing is created here)
             _lib.check(_lib.lib().difusco_profile_enable(1 if args.profile_all else 2, steps * (4 * LAYERS + 16)))
         fence()
         if sampler is not None:
             sampler.start()
+        if smu is not None:
+            smu.start()
         t0 = time.perf_counter()
         for i in range(steps):
             xt = one_step(warmup + rep * steps + i, xt)
@@ -688,6 +776,8 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         dt_r = time.perf_counter() - t0
         if sampler is not None:
             sampler.stop()
+        if smu is not None:
+            smu.stop()
         if not args.no_profile:     # this repetition's brackets (outside the timed region)
             ms = (ctypes.c_double * NCAT)()
             cnt = (ctypes.c_int64 * NCAT)()
@@ -711,6 +801,8 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         dist.all_gather(allr, mine)
         ranks_seen = len({int(v[0].item()) for v in allr})
         rank_ms = [float(v[1].item()) for v in allr]
+    if ranks_seen != world:      # (never print a line for fewer ranks than the command names)
+        raise SystemExit(f"bench.py: the collective gathered {ranks_seen} distinct ranks, the job has {world}")
 
     prof = None
     if not args.no_profile:      # the brackets of the REPORTED (median) repetition: every per-launch figure below belongs to it
@@ -724,7 +816,7 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
                 "MIS ER-[700,800] sparse categorical" if mis else f"TSP-{nodes} dense {wl['diffusion']}" if dense else
                 f"TSP-{nodes} k-NN sparse {wl['diffusion']}"),
             "value": value, "unit": "graph-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": {"fp16x3": "f32 (fp16x3 split MFMA, fp32 accumulate)", "bf16x3": "f32 (bf16x3 split MFMA, fp32 accumulate)",
                       "bf16x6": "f32 (bf16x6 split MFMA, fp32 accumulate)", "fp32": "f32 (fp32 MFMA)"}[args.precision],
@@ -754,6 +846,8 @@ def measure(args, workload, steps, warmup, cpu_steps, exact_fp32, rank, world, d
         }
         if sampler is not None:      # (N = 1: one socket; N > 1: rank 0's socket, graphs of rank 0)
             out["power"] = sampler.summary(dt / steps, G_local)
+            if smu is not None:
+                out["power"]["throttle"] = smu.summary()
         if prof is not None and prof["launches"][0] > 0:
             n_lin = prof["launches"][0]
             avg_s = prof["ms"][0] / n_lin * 1e-3

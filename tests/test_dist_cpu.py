@@ -116,3 +116,71 @@ def test_bench_py_multi_rank_plumbing_dry_run(gn_stats):
     rep = out["repeats"]
     assert rep["n"] == 3 and len(rep["ms_per_step"]) == 3
     assert rep["min_ms_per_step"] <= rep["median_ms_per_step"] == out["ms_per_step"] <= rep["max_ms_per_step"]
+
+
+def _run_bench(argv, env_extra=None, drop_env=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in drop_env}
+    env.update(BENCH_PLUMBING_DRY_RUN="1", BENCH_FULL_JSON=os.devnull)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, timeout=600,
+                          env=env, cwd=root)
+
+
+def test_bench_py_gpus_2_without_a_launcher_starts_two_ranks():
+    """``python bench.py --gpus 2`` with no launcher (WORLD_SIZE unset) must run TWO ranks - bench.py re-runs
+    itself under ``torch.distributed.run`` - and print the same keys as the launcher form, never an ``n_gpus: 1`` line."""
+    import json
+    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--nodes", "40", "--knn", "6", "--graphs-per-gpu", "3"]
+    res = _run_bench(argv)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and res.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and len(out["rank_ms_per_step"]) == 2 and out["dry_run"] is True
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 6 and out["config"]["graphs_per_gpu"] == 3
+    assert "starting 2 ranks" in res.stderr
+    # the launcher form of the same command: same keys, same configuration
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_PLUMBING_DRY_RUN="1", MASTER_ADDR="127.0.0.1", BENCH_FULL_JSON=os.devnull)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py")] + argv
+    res2 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert res2.returncode == 0, res2.stderr[-3000:]
+    out2 = json.loads([l for l in res2.stdout.splitlines() if l.startswith("{")][0])
+    assert sorted(out) == sorted(out2) and sorted(out["config"]) == sorted(out2["config"])
+    assert out2["n_gpus"] == 2 and out2["config"] == out["config"]
+
+
+def test_bench_py_refuses_a_rank_count_that_differs_from_the_command():
+    """A launcher that started ONE rank for a ``--gpus 2`` command (or two for ``--gpus 1``) is an error, not a one-rank line."""
+    for world, gpus in (("1", "2"), ("2", "1")):
+        res = _run_bench(["--gpus", gpus, "--steps", "2", "--warmup", "1", "--nodes", "40", "--knn", "6"],
+                         env_extra={"WORLD_SIZE": world, "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                    "MASTER_PORT": str(_free_port())}, drop_env=())
+        assert res.returncode != 0 and "refusing" in res.stderr, (res.returncode, res.stderr[-1000:])
+        assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
+    # outside the dry run a --gpus larger than the visible device count is refused before anything is launched
+    res = _run_bench(["--gpus", "2"], env_extra={"BENCH_PLUMBING_DRY_RUN": "0"})
+    assert res.returncode != 0 and not res.stdout.strip()
+
+
+def test_bench_py_strong_scaling_splits_the_literal_global_batch():
+    """``--scaling strong``: BASELINE configs[2]'s batch (here --global-batch 5) is split over the ranks by shard_range (3 + 2),
+    the line says ``strong`` and value counts the GLOBAL batch."""
+    import json
+    res = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--nodes", "40", "--knn", "6", "--scaling", "strong",
+                      "--global-batch", "5"])
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert out["config"]["global_batch"] == 5 and out["config"]["graphs_per_gpu"] == 3 and out["config"]["nodes_rank0"] == 120
+    assert abs(out["value"] - 5 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    # fewer graphs than ranks: refused
+    res = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--nodes", "40", "--knn", "6", "--scaling", "strong",
+                      "--global-batch", "1"])
+    assert res.returncode != 0
