@@ -87,6 +87,7 @@ def lib():
     L.difusco_prepared_bytes.argtypes = [i32, i32]
     L.difusco_prepare.argtypes = [ctypes.POINTER(StepArgs), vp, ctypes.c_size_t]
     L.difusco_time_bias_rows.argtypes = [i32, i32, i32, f32p, ctypes.POINTER(ctypes.c_float), i32, f32p, vp]
+    L.difusco_edge_embed.argtypes = [i32, i32, i32, f32p, i32, f32p, vp, i64, f32p, f32p, vp]
     L.difusco_linear_rows.argtypes = [f32p, f32p, f32p, f32p, f32p, i64, i32, i32, i64, vp]
     L.difusco_linear_rows_split.argtypes = [f32p, vp, i32, f32p, f32p, f32p, i64, i32, i32, i64, f32p, vp]
     L.difusco_fused_scratch_bytes.restype = ctypes.c_size_t

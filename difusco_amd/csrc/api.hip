@@ -542,6 +542,27 @@ int difusco_time_bias_rows(int hidden, int n_layers, int out_channels, const flo
   return DIFUSCO_OK;
 }
 
+// e0 = edge_embed(ScalarEmbeddingSine(x_t)) for a general (Gaussian / non-binary) x_t, by the kernel the fused step uses (edge_embed.hip):
+// exported for the parity tests (partial tiles, permuted inputs, |x_t| up to 6).
+int difusco_edge_embed(int hidden, int n_layers, int out_channels, const float* weights, int precision, const float* xt,
+                       const int32_t* perm, int64_t n_edges, float* e_tiled, float* tile_max, void* stream) {
+  using namespace difusco;
+  if (hidden != 256) return fail(DIFUSCO_EINVAL, "difusco_edge_embed: the tiled kernel exists for hidden = 256");
+  if (n_layers < 1 || (out_channels != 1 && out_channels != 2)) return fail(DIFUSCO_EINVAL, "n_layers >= 1, out_channels in {1,2} required");
+  if (precision != DIFUSCO_PREC_BF16X3 && precision != DIFUSCO_PREC_FP16X3)
+    return fail(DIFUSCO_EINVAL, "difusco_edge_embed: precision must be BF16X3 or FP16X3");
+  if (!weights || !xt || !e_tiled || n_edges < 0 || n_edges > 0x7fffffff) return fail(DIFUSCO_EINVAL, "null pointer / bad n_edges");
+  const Layout lo = make_layout(hidden, n_layers, out_channels);
+  auto G = [&](int id) { return weights + lo.off[id]; };
+  const int H = hidden;
+  const bool f16 = precision == DIFUSCO_PREC_FP16X3;
+  const unsigned short* pl = reinterpret_cast<const unsigned short*>(G(DIFUSCO_W_EDGE_EMBED_PLANES)) + (f16 ? (long long)3 * H * H : 0);
+  HIP_TRY(launch_edge_embed_tiled(xt, perm, G(DIFUSCO_W_DIMT_SCALAR), pl, (long long)H * H, precision,
+                                  f16 ? G(DIFUSCO_W_EDGE_EMBED_PLANES) + (long long)5 * H * H / 2 : nullptr, G(DIFUSCO_W_EDGE_EMBED_B),
+                                  e_tiled, n_edges, tile_max, (hipStream_t)stream));
+  return DIFUSCO_OK;
+}
+
 // The step-invariant part of a TSP step, with the kernels (and therefore the bits) of the stateless step: node embedding,
 // row scales, layer 0's node linear, the two-row edge-input table and C of layer 0 applied to it.
 int difusco_prepare(const difusco_step_args* a, void* prepared, size_t prepared_bytes) {

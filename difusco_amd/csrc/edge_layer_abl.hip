@@ -22,6 +22,12 @@ hipError_t launch_fused_ablation(int mask, FUSED_KIND_PARAMS) {
     case 35: return launch_fused_t<FFp16, 16 + 1024 + 2048, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // stamps, no gather requests, no waits
     case 36: return launch_fused_t<FFp16, 1024, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // (no stamps) gather requests never waited for
     case 37: return launch_fused_t<FFp16, 1024 + 2048, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // (no stamps) no gather requests, no waits
+    // round 6, traffic attribution (profiles/r06/reread_attribution.txt): ONE access class off at a time, production options, no stamps
+    case 38: return launch_fused_t<FFp16, 16384, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // no weight-stage refills / barriers (stale LDS)
+    case 39: return launch_fused_t<FFp16, 32768, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // no e stream into GEMM 1
+    case 40: return launch_fused_t<FFp16, 32, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);      // no residual read, no e store
+    case 41: return launch_fused_t<FFp16, 128, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);     // no B h[i] loads
+    case 42: return launch_fused_t<FFp16, 128 + 1024 + 2048, FUSED_NW, false, false, 0, FUSED_OPT>(ABL_ARGS, ABL_TAIL);   // no node-table access at all
     case 22: return launch_fused_t<FFp16, 16 + 32768, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // stamps, no e stream
     case 23: return launch_fused_t<FFp16, 16 + 16384, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);   // stamps, no stage refills / barriers
     case 24: return launch_fused_t<FFp16, 16 + 1, FUSED_NW, false, false, 0, FUSED_OPT_R2>(ABL_ARGS, ABL_TAIL);       // stamps, no gathers

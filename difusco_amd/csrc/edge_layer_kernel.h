@@ -641,7 +641,7 @@ _Pragma("unroll")                                                               
   // One buffer, the two tables alternate: A(nb) is read, V(nb) requested, the gate's e' / sigmoid computed, V(nb) read,
   // A(nb + 1) requested, the messages formed.  Every wait is vmcnt(0): stores share the counter on gfx9.
   constexpr bool kFL = (OPT & 16384) != 0;
-  static_assert(!kFL || (ablate & 0x3EF) == 0, "OPT bit 14 is written for the production arithmetic");
+  static_assert(!kFL || (ablate & 0x30F) == 0, "OPT bit 14 is written for the production arithmetic");      // (bits 5-7: GEMM 2 output path / B h[i] loads off - traffic attribution, round 6)
   // ABL 1024 / 2048 (profiling library, wrong results): the full-line gather requests are issued but never waited for / not
   // issued at all - what the waits and what the issue of the 64 LDS-DMA pieces cost in the gather phase
   // OPT bit 15 (with bit 14): TWO units - A in the wave's share of buffer 1, V in its share of buffer 0 - so that the next block
@@ -701,8 +701,11 @@ _Pragma("unroll")                                                               
     const int b_voff = i_node * (4 * H * 4) + hh * 16;
 #define FUSED_FL_B(nb_, buf)                                                                          \
   {                                                                                                   \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                     \
-      bh_[buf][g] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_n, b_voff, (3 * H + 32 * (nb_) + 8 * g) * 4, 0)); \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
+      if constexpr ((ablate & 128) == 0)                                                              \
+        bh_[buf][g] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs_n, b_voff, (3 * H + 32 * (nb_) + 8 * g) * 4, 0)); \
+      else bh_[buf][g] = v4f{0.f, 0.f, 0.f, 0.f};      /* (ABL 128, timing / traffic attribution only: no B h[i] loads) */ \
+    }                                                                                                 \
   }
     FUSED_FL_B(0, 0)
     FUSED_FL_REQUEST(2, 0, 0)

@@ -238,6 +238,15 @@ int difusco_prepare(const difusco_step_args* args, void* prepared, size_t prepar
 int difusco_time_bias_rows(int hidden, int n_layers, int out_channels, const float* weights, const float* t_host, int n_t,
                            float* out, void* stream);
 
+/* e0 = edge_embed(ScalarEmbeddingSine(x_t)) (difusco/models/gnn_encoder.py:230-249 the features, :304,:395 the linear) for a
+ * GENERAL x_t (Gaussian diffusion; a categorical x_t that is not exactly {0,1}) - the kernel the fused step runs for such inputs,
+ * exported for parity tests.  hidden = 256; precision = DIFUSCO_PREC_BF16X3 | _FP16X3.  xt [n_edges] in caller order, perm (or
+ * NULL) maps CSR slot -> caller index; e_tiled: the TILED edge state (layout at difusco_edge_layer_fused below), padded to a multiple of 256 rows
+ * (only the n_edges real rows are written); tile_max (or NULL): one float per 32-edge tile of the padded range = max |e0| of the
+ * tile (0 for tiles past the end). */
+int difusco_edge_embed(int hidden, int n_layers, int out_channels, const float* weights, int precision, const float* xt,
+                       const int32_t* perm, int64_t n_edges, float* e_tiled, float* tile_max, void* stream);
+
 /* One reverse-diffusion step: GNN denoiser forward + posterior (+ sample).  Asynchronous on
  * args->stream.  Replaces {categorical,gaussian}_denoise_step of pl_tsp_model.py / pl_mis_model.py. */
 int difusco_denoise_step(const difusco_step_args* args);

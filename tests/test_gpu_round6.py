@@ -1,0 +1,187 @@
+"""GPU parity tests added in round 6 (``-m gpu``), VERDICT r5 "next" #3.
+
+* TRAINED-NETWORK STATISTICS.  Every earlier adversarial case multiplies whole parameter groups by one power of two; a trained
+  checkpoint looks different: a few outlier channels in the LayerNorm affines, a residual stream whose norm grows layer by layer,
+  heavy-tailed weight matrices.  Three such classes x the three step kinds, default engine (fused kernel, fp16x3 planes with per-tile /
+  per-matrix power-of-two operand scales).  The bound is CALIBRATED against the same network evaluated in float64
+  (``oracle.encoder_sparse_f64``): where the fp32 oracle itself sits further than 1e-5 from the float64 value (two faithful fp32
+  evaluations of such a network do not agree to 1e-5), the HIP path must be no further from float64 than 3 x the oracle is;
+  everywhere else it must meet the 1e-5 class against the fp32 oracle directly.
+* ``edge_embed_tiled_kernel`` through its own C entry (``difusco_edge_embed``): partial tiles and partial workgroups
+  (E in {31, 33, 127, 129, 4099}), permuted inputs, |x_t| up to 6, at the 1e-5 class (reference: gnn_encoder.py:230-249, :304, :395).
+* the tie band of the sampled-bit comparison follows the bound that is asserted.
+"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import difusco_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # north_star's bound
+CLASS_TOL = 1e-5    # the default engine's class
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+def _args(kind, sparse_factor=8, trick="ddim", H=256, L=12):
+    return dict(diffusion_type=kind, diffusion_schedule="linear", diffusion_steps=1000, sparse_factor=sparse_factor,
+                n_layers=L, hidden_dim=H, inference_trick=trick)
+
+
+def _student_t(shape, nu, g):
+    z = torch.randn(shape, generator=g)
+    chi = torch.randn((nu,) + tuple(shape), generator=g).pow(2).sum(0) / nu
+    return z / chi.sqrt()
+
+
+def trained_like_params(kind, H, L, C, seed):
+    """Random-init parameters bent towards what training produces (difusco/models/gnn_encoder.py:58-65 LayerNorm affines,
+    :339-347 per_layer_out; pl_tsp_model.py:140-151 consumes whatever the checkpoint holds)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    p = {k: v.clone() for k, v in O.init_params(H, L, C, seed=seed).items()}
+    if kind == "outlier_channels":       # 4 of 256 features: gains x 64, biases x 16, in both LayerNorms of every layer
+        for l in range(L):
+            idx = torch.randperm(H, generator=g)[:4]
+            for nm in (f"layers.{l}.norm_e", f"per_layer_out.{l}.0"):
+                p[nm + ".weight"][idx] *= 64.0
+                p[nm + ".bias"][idx] *= 16.0
+    elif kind == "growing_residual":     # per_layer_out[l][2] x 4^(l+1): the rms of e grows ~4x per layer (2 -> 7.6e6 over 12 layers)
+        for l in range(L):
+            p[f"per_layer_out.{l}.2.weight"] *= 4.0 ** (l + 1)
+            p[f"per_layer_out.{l}.2.bias"] *= 4.0 ** (l + 1)
+    elif kind == "heavy_tailed":         # Student-t (nu = 3) entries for C and per_layer_out[l][2], same variance scale as the default init
+        for l in range(L):
+            for nm in (f"layers.{l}.C", f"per_layer_out.{l}.2"):
+                p[nm + ".weight"] = _student_t((H, H), 3, g) / math.sqrt(3.0 * H)
+    else:
+        raise ValueError(kind)
+    return p
+
+
+@pytest.mark.parametrize("weights_kind", ["outlier_channels", "growing_residual", "heavy_tailed"])
+@pytest.mark.parametrize("step", ["tsp_categorical", "tsp_gaussian", "mis_categorical"])
+def test_default_engine_on_trained_like_weights(dev, step, weights_kind):
+    from difusco_amd import MISModel, TSPModel
+    H, L = 256, 12
+    C = 1 if step == "tsp_gaussian" else 2
+    p = trained_like_params(weights_kind, H, L, C, seed=91)
+    g = torch.Generator().manual_seed(17)
+    t, tt = 500, 469
+    tvec = torch.tensor([float(t)])
+    if step == "mis_categorical":
+        ei = torch.from_numpy(O.er_mis_instance(300, 0.06, seed=5))
+        xt = (torch.randn(300, generator=g) > 0).float()
+        u = torch.rand(300, generator=g)
+        ref_x, ref, ref_prob = O.mis_categorical_denoise_step(p, O.CategoricalTables(), xt, t, ei, tt, uniform=u, return_aux=True)
+        truth = O.encoder_sparse_f64(p, None, xt, tvec, ei, node_feature_only=True)
+        m = MISModel(_args("categorical", -1), p, device=dev)
+        out_x, out, prob = m.categorical_denoise_step(xt.to(dev), np.array([t]), dev, ei.to(dev), target_t=np.array([tt]), uniform=u,
+                                                      return_aux=True)
+    else:
+        pts, ei = O.tsp_instance(150, 20, seed=6)      # 3,000 edges: 94 tiles, the last one partial (24 of 32 edges)
+        pts, ei = torch.from_numpy(pts), torch.from_numpy(ei)
+        if step == "tsp_categorical":
+            xt = (torch.randn(ei.shape[1], generator=g) > 0).float()
+            u = torch.rand(ei.shape[1], generator=g)
+            ref_x, ref, ref_prob = O.tsp_categorical_denoise_step(p, O.CategoricalTables(), pts, xt, t, ei, tt, uniform=u, return_aux=True)
+            m = TSPModel(_args("categorical", 20), p, device=dev)
+            out_x, out, prob = m.categorical_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev), target_t=np.array([tt]),
+                                                          uniform=u, return_aux=True)
+        else:
+            xt = torch.randn(ei.shape[1], generator=g)
+            u = None
+            ref_x, ref = O.tsp_gaussian_denoise_step(p, O.GaussianTables(), pts, xt, t, ei, tt, return_aux=True)[:2]
+            m = TSPModel(_args("gaussian", 20), p, device=dev)
+            out_x, out = m.gaussian_denoise_step(pts.to(dev), xt.to(dev), np.array([t]), dev, ei.to(dev), target_t=np.array([tt]),
+                                                 return_aux=True)
+            prob = ref_prob = None
+        truth = O.encoder_sparse_f64(p, pts, xt, tvec, ei)
+    assert torch.isfinite(out).all()
+    got = out.cpu().reshape(ref.shape)
+    e_hip_ref = (got - ref).abs().max().item()
+    e_ref_true = (ref.double() - truth.reshape(ref.shape)).abs().max().item()
+    e_hip_true = (got.double() - truth.reshape(ref.shape)).abs().max().item()
+    print(f"{step} {weights_kind}: |out| max {ref.abs().max().item():.2e}; HIP vs fp32 oracle {e_hip_ref:.2e}; fp32 oracle vs float64 "
+          f"{e_ref_true:.2e}; HIP vs float64 {e_hip_true:.2e}")
+    # the class bound, calibrated: against float64 the HIP path may sit at the 1e-5 class or at 3 x the fp32 oracle's own distance
+    assert e_hip_true < max(CLASS_TOL, 3.0 * e_ref_true), (e_hip_true, e_ref_true)
+    if e_ref_true < CLASS_TOL / 3:      # the fp32 oracle is a usable arbiter at the class: direct comparison
+        assert e_hip_ref < CLASS_TOL, e_hip_ref
+        if prob is not None:
+            e_prob = (prob.cpu().reshape(-1) - ref_prob.reshape(-1)).abs().max().item()
+            assert e_prob < CLASS_TOL, e_prob
+            safe = (u - ref_prob.reshape(-1)).abs() > CLASS_TOL      # tie band = the bound asserted on prob
+            assert torch.equal(out_x.cpu().reshape(-1)[safe], ref_x.reshape(-1)[safe])
+        else:
+            assert (out_x.cpu().reshape(-1) - ref_x.reshape(-1)).abs().max().item() < CLASS_TOL
+
+
+@pytest.mark.parametrize("precision,bound", [("fp16x3", CLASS_TOL), ("bf16x3", TOL)])
+@pytest.mark.parametrize("E", [31, 33, 127, 129, 4099])
+def test_edge_embed_kernel_partial_tiles_permuted(dev, E, precision, bound):
+    """``difusco_edge_embed``: e0 = edge_embed(ScalarEmbeddingSine(x_t)) on E edges that do not fill a tile / a workgroup, inputs
+    reached through a non-identity permutation, |x_t| up to 6 (Gaussian x_t lives in about +-5); the rows past E stay untouched and
+    the per-tile maxima equal the maxima of what was written."""
+    from difusco_amd import _lib, graph, weights
+    H, Lyr, C = 256, 1, 1
+    p = O.init_params(H, Lyr, C, seed=123)
+    blob = weights.pack_state_dict(p).to(dev)
+    g = torch.Generator().manual_seed(E)
+    x_slot = (torch.rand(E, generator=g) * 12.0 - 6.0)
+    x_slot[0], x_slot[-1] = 6.0, -6.0
+    perm = torch.randperm(E, generator=g).to(torch.int32)        # CSR slot s reads caller index perm[s]
+    x_caller = torch.empty(E)
+    x_caller[perm.long()] = x_slot
+    ref = O._lin(p, "edge_embed", O.scalar_embedding_sine(x_slot, H))
+    E_pad = (E + 255) // 256 * 256
+    e_t = torch.full((E_pad * H,), 7.0, device=dev)
+    tmax = torch.full((E_pad // 32,), -1.0, device=dev)
+    L = _lib.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    xc, pm = x_caller.to(dev), perm.to(dev)
+    _lib.check(L.difusco_edge_embed(H, Lyr, C, P(blob), _lib.PRECISIONS[precision], P(xc), P(pm), E, P(e_t), P(tmax),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = graph.from_tiled(e_t, E).cpu()
+    err = (got - ref).abs().max().item()
+    print(f"edge_embed {precision} E={E}: L_inf {err:.2e} (|e0| max {ref.abs().max().item():.2f})")
+    assert err < bound, err
+    # rows past E: never written
+    off = graph.edge_tiled_offsets(E_pad).to(dev)
+    if E_pad > E:
+        assert bool((e_t[off[E:].reshape(-1)] == 7.0).all())
+    # tile maxima: tiles that hold edges report max |e0| of their rows; the pad tiles of the last workgroup report 0, later ones are untouched
+    n_tiles, n_wg_tiles = (E + 31) // 32, (E + 127) // 128 * 4
+    tm = tmax.cpu()
+    for tl in range(n_tiles):
+        rows = got[tl * 32:min(E, tl * 32 + 32)]
+        assert abs(tm[tl].item() - rows.abs().max().item()) == 0.0
+    assert bool((tm[n_tiles:n_wg_tiles] == 0.0).all()) and bool((tm[n_wg_tiles:] == -1.0).all())
+    # identity permutation given as NULL: same bits
+    e_t2 = torch.zeros_like(e_t)
+    xs = x_slot.to(dev)
+    _lib.check(L.difusco_edge_embed(H, Lyr, C, P(blob), _lib.PRECISIONS[precision], P(xs), None, E, P(e_t2), None,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(graph.from_tiled(e_t2, E).cpu(), got)
+
+
+def test_edge_embed_rejects_bad_arguments(dev):
+    from difusco_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(64, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    assert L.difusco_edge_embed(128, 1, 1, P(x), 3, P(x), None, 64, P(x), None, None) < 0          # hidden != 256
+    assert L.difusco_edge_embed(256, 1, 1, P(x), 0, P(x), None, 64, P(x), None, None) < 0          # fp32: no tiled kernel
+    assert L.difusco_edge_embed(256, 1, 1, None, 3, P(x), None, 64, P(x), None, None) < 0
+    assert L.difusco_edge_embed(256, 1, 1, P(x), 3, P(x), None, 0, P(x), None, None) == 0          # empty: nothing to do
