@@ -54,8 +54,9 @@ def test_golden_dense_mean_max_vs_the_imported_reference(dev, agg, H, L, B, fuse
         assert err < TOL, f"step {i}: logits L_inf {err}"
         if tt > 0:
             ref_p = z[f"cat{i}_prob"].reshape(-1)
-            assert np.abs(prob.cpu().numpy().reshape(-1) - ref_p).max() < TOL
-            safe = np.abs(z[f"cat{i}_uniform"].reshape(-1) - ref_p) > 1e-5
+            e_prob = float(np.abs(prob.cpu().numpy().reshape(-1) - ref_p).max())
+            assert e_prob < TOL
+            safe = np.abs(z[f"cat{i}_uniform"].reshape(-1) - ref_p) > max(1e-5, e_prob)      # tie band: a bit can flip only inside the observed |prob| error
             np.testing.assert_array_equal(out.cpu().numpy().reshape(-1)[safe], z[f"cat{i}_out"].reshape(-1)[safe])
     mg = TSPModel(_args("gaussian", -1, agg, H, L), gau, device=dev, fused=fused)
     for i in range(2):
@@ -95,7 +96,7 @@ def test_sparse_tsp_mean_max_vs_oracle(dev, H, Lyr, N, K, G, agg, fused, backend
     e_log, e_prob = (lg.cpu() - ref_logits).abs().max().item(), (pr.cpu() - ref_prob.reshape(-1)).abs().max().item()
     print(f"TSP N={N} K={K} G={G} H={H} {agg} fused={fused} {backend}: logits L_inf {e_log:.2e}, prob L_inf {e_prob:.2e}")
     assert e_log < TOL and e_prob < TOL
-    safe = (u - ref_prob.reshape(-1)).abs() > 1e-5
+    safe = (u - ref_prob.reshape(-1)).abs() > max(1e-5, e_prob)      # tie band: 1e-5, or the observed prob error of this (TOL-bounded) call
     assert torch.equal(out.cpu()[safe], ref_out[safe])
     # Gaussian model of the same shape, one DDIM step
     pg = O.init_params(H, Lyr, 1, seed=H + N + 1)
@@ -131,7 +132,7 @@ def test_mis_mean_max_vs_oracle_with_an_isolated_node(dev, agg, fused):
     e_log, e_prob = (lg.cpu() - ref_logits).abs().max().item(), (pr.cpu() - ref_prob.reshape(-1)).abs().max().item()
     print(f"MIS n={n} ({ei.shape[1]} edges, node {lone} isolated) {agg} fused={fused}: logits L_inf {e_log:.2e}, prob L_inf {e_prob:.2e}")
     assert e_log < TOL and e_prob < TOL
-    safe = (u - ref_prob.reshape(-1)).abs() > 1e-5
+    safe = (u - ref_prob.reshape(-1)).abs() > max(1e-5, e_prob)      # tie band: 1e-5, or the observed prob error of this (TOL-bounded) call
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 

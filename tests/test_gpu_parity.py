@@ -16,6 +16,7 @@ from oracle import difusco_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+CLASS_TOL = 1e-5    # the bound class of the fp32-class engines (fp32, bf16x6, fp16x3); bf16x3 is held to TOL
 
 
 @pytest.fixture(scope="module")
@@ -360,8 +361,10 @@ def _check_cat(z, i, out, logits, prob, order=None):
     assert err < TOL, f"logits L_inf {err}"
     if tt > 0:
         ref_p = z[f"cat{i}_prob"].reshape(-1)
-        assert np.abs(prob.cpu().numpy().reshape(-1) - ref_p).max() < TOL
-        safe = np.abs(z[f"cat{i}_uniform"].reshape(-1) - ref_p) > 1e-5
+        e_prob = float(np.abs(prob.cpu().numpy().reshape(-1) - ref_p).max())
+        assert e_prob < TOL
+        # tie band: 1e-5 for the fp32-class engines; a TOL-bounded engine (bf16x3) may flip a bit only inside ITS observed error
+        safe = np.abs(z[f"cat{i}_uniform"].reshape(-1) - ref_p) > max(1e-5, e_prob)
         np.testing.assert_array_equal(out.cpu().numpy().reshape(-1)[safe], z[f"cat{i}_out"].reshape(-1)[safe])
     else:
         assert np.abs(out.cpu().numpy().reshape(-1) - z[f"cat{i}_out"].reshape(-1)).max() < TOL
@@ -467,7 +470,7 @@ def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
         print(f"{prec} H={H} L={Lyr} t={t}: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
         assert e_log < TOL and e_prob < TOL
         if tt > 0:
-            safe = (u - ref_prob.reshape(-1)).abs() > 1e-5
+            safe = (u - ref_prob.reshape(-1)).abs() > max(1e-5, e_prob)      # (the band follows the observed error of a TOL-bounded engine)
             assert torch.equal(out.cpu()[safe], ref_out[safe])
         else:
             assert (out.cpu() - ref_out).abs().max().item() < TOL
@@ -478,7 +481,9 @@ def test_oracle_tsp_full_width(dev, H, Lyr, N, K, G, prec):
     out, logits, prob = m.categorical_denoise_step(pts.to(dev), xt_s.to(dev), np.array([500]), dev, ei_s.to(dev),
                                                    target_t=np.array([400]), uniform=u_s, return_aux=True)
     assert (logits.cpu() - ref_logits).abs().max().item() < TOL
-    safe = (u_s - ref_prob.reshape(-1)).abs() > 1e-5
+    e_prob = (prob.cpu() - ref_prob.reshape(-1)).abs().max().item()
+    assert e_prob < TOL
+    safe = (u_s - ref_prob.reshape(-1)).abs() > max(1e-5, e_prob)
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 
@@ -501,8 +506,10 @@ def test_oracle_tsp_gaussian_full_width(dev, prec):
                                                 noise=z, return_aux=True)
             e_pred = (pred.cpu() - ref_pred).abs().max().item()
             print(f"{prec} gaussian t={t}: eps L_inf {e_pred:.3e}")
-            assert e_pred < TOL
-            assert (out.cpu() - ref_out).abs().max().item() < TOL
+            # (N = 80, K = 12: 960 edges = 7.5 workgroups of the generated-input embedding kernel, partial tile + partial workgroup)
+            tol = TOL if prec.startswith("bf16x3") else CLASS_TOL
+            assert e_pred < tol
+            assert (out.cpu() - ref_out).abs().max().item() < tol
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
@@ -843,8 +850,9 @@ def test_golden_tsp50_dense_full_width_all_50_steps(dev, golden_dir):
         ref_logits = np.transpose(z["logits"][i], (0, 2, 3, 1))
         worst_l = max(worst_l, float(np.abs(logits.cpu().numpy().reshape(ref_logits.shape) - ref_logits).max()))
         if tt > 0:
-            worst_p = max(worst_p, float(np.abs(prob.cpu().numpy().reshape(-1) - z["prob"][i].reshape(-1)).max()))
-            safe = np.abs(z["uniform"][i].reshape(-1) - z["prob"][i].reshape(-1)) > 1e-5
+            e_prob = float(np.abs(prob.cpu().numpy().reshape(-1) - z["prob"][i].reshape(-1)).max())
+            worst_p = max(worst_p, e_prob)
+            safe = np.abs(z["uniform"][i].reshape(-1) - z["prob"][i].reshape(-1)) > max(1e-5, e_prob)
             np.testing.assert_array_equal(out.cpu().numpy().reshape(-1)[safe], z["out"][i].reshape(-1)[safe])
         else:
             assert np.abs(out.cpu().numpy().reshape(-1) - z["out"][i].reshape(-1)).max() < TOL
@@ -961,7 +969,7 @@ def test_bench_workload_tsp1000_oracle_and_batch(dev):
     e_log, e_prob = (l1.cpu() - ref_logits).abs().max().item(), (p1.cpu() - ref_prob.reshape(-1)).abs().max().item()
     print(f"TSP-1000 K=100 H=256 L=12, one graph vs oracle: logits L_inf {e_log:.3e}, prob L_inf {e_prob:.3e}")
     assert e_log < TOL and e_prob < TOL
-    safe = (u1 - ref_prob.reshape(-1)).abs() > 1e-5
+    safe = (u1 - ref_prob.reshape(-1)).abs() > max(1e-5, e_prob)
     assert torch.equal(out1.cpu()[safe], ref_out[safe])
     # (2) the benched call shape with replicas
     pts = pts1.repeat(G, 1).to(dev)
@@ -1229,9 +1237,9 @@ def test_categorical_step_with_non_binary_xt(dev, H, Lyr, prec):
                                                        target_t=np.array([tt]), uniform=u, return_aux=True)
         e_log, e_prob = (logits.cpu() - ref_logits).abs().max().item(), (prob.cpu() - ref_prob.reshape(-1)).abs().max().item()
         print(f"non-binary x_t, TSP {prec} H={H} t={t}: logits L_inf {e_log:.2e}, prob L_inf {e_prob:.2e}")
-        assert e_log < TOL and e_prob < TOL
+        assert e_log < CLASS_TOL and e_prob < CLASS_TOL      # (fp16x3 fused / unfused and exact fp32: the fp32 class; N = 50, K = 8: 400 edges, partial tiles)
         if tt > 0:
-            safe = (u - ref_prob.reshape(-1)).abs() > 1e-5
+            safe = (u - ref_prob.reshape(-1)).abs() > max(1e-5, e_prob)
             assert torch.equal(out.cpu()[safe], ref_out[safe])
     # the binary fast path and the general path agree on binary input (same model, x_t given as 0/1 floats vs ints)
     xb = (xt >= 1).float()
@@ -1248,8 +1256,9 @@ def test_categorical_step_with_non_binary_xt(dev, H, Lyr, prec):
     ref_out, ref_logits, ref_prob = O.mis_categorical_denoise_step(p, tab, xm, 600, eim, 560, uniform=um, return_aux=True)
     out, logits, prob = mm.categorical_denoise_step(xm.to(dev), np.array([600]), dev, eim.to(dev), target_t=np.array([560]),
                                                     uniform=um, return_aux=True)
-    assert (logits.cpu() - ref_logits).abs().max().item() < TOL and (prob.cpu() - ref_prob.reshape(-1)).abs().max().item() < TOL
-    safe = (um - ref_prob.reshape(-1)).abs() > 1e-5
+    e_prob = (prob.cpu() - ref_prob.reshape(-1)).abs().max().item()
+    assert (logits.cpu() - ref_logits).abs().max().item() < TOL and e_prob < TOL
+    safe = (um - ref_prob.reshape(-1)).abs() > max(1e-5, e_prob)
     assert torch.equal(out.cpu()[safe], ref_out[safe])
 
 

@@ -220,7 +220,7 @@ def test_tsp1000_x64_single_call(dev):
     e_fu = (la - lc).abs().max().item()
     print(f"64 x TSP-1000 in one call (E = {E}): fused vs unfused logits L_inf {e_fu:.3e}, prob L_inf {(pa - pc).abs().max().item():.3e}")
     assert e_fu < 5e-5 and (pa - pc).abs().max().item() < 5e-5
-    safe = ((u.to(dev) - pa).abs() > 1e-5)
+    safe = ((u.to(dev) - pa).abs() > max(1e-5, (pa - pc).abs().max().item()))      # (fused vs unfused, bounded by 5e-5: the band follows the observed difference)
     assert torch.equal(a[safe], c[safe])
 
 
