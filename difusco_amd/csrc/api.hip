@@ -608,9 +608,14 @@ int difusco_prepare(const difusco_step_args* a, void* prepared, size_t prepared_
     HIP_TRY(linear_rows_split(prep.h0, npl, (long long)4 * H * H, a->precision,
                               LW(0, fused_prec ? DIFUSCO_WL_NODE4_FUSED_B : DIFUSCO_WL_NODE4_B), nullptr,
                               prep.node4_0, N, H, 4 * H, 4 * H, st, 0, sc));
+    //  a precision without a fused path (BF16X6) computes the reference's rows: converted in place, so that the buffer
+    // is in the fused kernel's domain WHATEVER precision prepared it - a step that runs a fused precision on it then differs by
+    // the rounding of the node linear only (as under ABI 10), never by a missing b_C / log2(e)
+    if (!fused_prec) HIP_TRY(launch_fuse_node_tables(prep.node4_0, LW(0, DIFUSCO_WL_C_B), (int)N, prep.node4_0, st));
   } else {
     HIP_TRY(linear_rows(prep.h0, LW(0, DIFUSCO_WL_NODE4_W), LW(0, DIFUSCO_WL_NODE4_B), nullptr, prep.node4_0, N, H, 4 * H,
                         4 * H, st));
+    if (H == 256) HIP_TRY(launch_fuse_node_tables(prep.node4_0, LW(0, DIFUSCO_WL_C_B), (int)N, prep.node4_0, st));      // (FP32: same rule)
   }
   // two-row edge-input table of a categorical step (embedding of the bit) and C of layer 0 applied to it
   HIP_TRY(launch_scalar_embed(nullptr, nullptr, G(DIFUSCO_W_DIMT_SCALAR), 2, H, ws.table_in, st));

@@ -27,6 +27,26 @@ def _op_call(fn, *args):
         raise
 
 
+class _ReadyEvent:
+    """Cross-stream ordering for cached device buffers that were produced asynchronously: an event recorded on the producing stream
+    right behind the producing launch; a consumer on another stream waits for it ONCE (later work of that stream is ordered behind
+    the wait anyway).  The producing stream itself never waits (stream order), which also keeps a HIP-graph capture on that stream free
+    of foreign events."""
+
+    def __init__(self, device):
+        self.device = device
+        st = torch.cuda.current_stream(device)
+        self.event = torch.cuda.Event()
+        self.event.record(st)
+        self.ordered = {st.cuda_stream}
+
+    def wait_on_current_stream(self):
+        st = torch.cuda.current_stream(self.device)
+        if st.cuda_stream not in self.ordered:
+            st.wait_event(self.event)
+            self.ordered.add(st.cuda_stream)
+
+
 class DenoiseEngine:
     def __init__(self, state_dict=None, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
                  fused: bool = True, backend: Optional[str] = None, flags: int = 0, config=None, aggregation: str = "sum"):
@@ -82,7 +102,7 @@ class DenoiseEngine:
                     "use backend='ctypes' with the profiling library / DIFUSCO_HIP_LIBRARY")
             self._ops = torch_ops.load()
         self._ws = {}               # HIP stream -> workspace tensor
-        self._tbias = {}            # (HIP stream, t) -> [n_layers, hidden] time-bias rows on the device (prepare_times)
+        self._tbias = {}            # t -> ([n_layers, hidden] time-bias rows on the device, _ReadyEvent) (prepare_times)
         self.calls = 0
 
     # ---- workspace -----------------------------------------------------------------------------
@@ -109,10 +129,11 @@ class DenoiseEngine:
     def prepare_times(self, ts) -> None:
         """Time-bias rows of every diffusion time in ``ts`` (e.g. the 50 steps of a schedule) in ONE launch; ``step`` then
         passes the row block of its ``t`` instead of running the time MLP (``gnn_encoder.py:396,329-337``)."""
-        # (cached per HIP stream, like the workspace: the rows are produced asynchronously on the current stream, and a step on
-        #  another stream must not read them before that launch has finished)
-        sid = torch.cuda.current_stream(self.device).cuda_stream
-        todo = sorted({float(t) for t in ts} - {t for (s_, t) in self._tbias if s_ == sid})
+        # The rows are produced asynchronously on the stream that is current HERE; each cache entry carries an event recorded
+        # behind that launch, and a step on ANOTHER stream waits for the event once (ADVICE r5 #3: the key is the time alone - a
+        # raw stream handle can be reused by a new stream after the old one is destroyed, and an eviction no longer drops the
+        # rows of every other stream)
+        todo = sorted({float(t) for t in ts} - set(self._tbias))
         if not todo:
             return
         if self.backend == "torch":
@@ -124,10 +145,11 @@ class DenoiseEngine:
                 _lib.check(_lib.lib().difusco_time_bias_rows(
                     self.hidden, self.n_layers, self.out_channels, _ptr(self.blob), arr, len(todo), _ptr(out),
                     ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
-        if len(self._tbias) > 4096:
-            self._tbias.clear()
+        ready = _ReadyEvent(self.device)
+        while len(self._tbias) + len(todo) > 4096 and self._tbias:      # oldest first (dicts keep insertion order)
+            self._tbias.pop(next(iter(self._tbias)))
         for i, t in enumerate(todo):
-            self._tbias[(sid, t)] = out[i]
+            self._tbias[t] = (out[i], ready)
 
     def _uses_prepared(self, g: CsrGraph) -> bool:
         """Will ``difusco_denoise_step`` read a prepared buffer for a call on graph ``g``?  The C side's ``fused`` predicate
@@ -135,12 +157,12 @@ class DenoiseEngine:
         return (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3") and g.n_edges > 0
                 and not (self.aggregation == "max" and g.n_nodes >= (1 << 20)))
 
-    def prepare(self, g: CsrGraph, points: torch.Tensor) -> Optional[torch.Tensor]:
+    def prepare(self, g: CsrGraph, points: torch.Tensor, force: bool = False) -> Optional[torch.Tensor]:
         """The step-invariant part of a TSP step for (these weights, this graph, these coordinates) - node embedding,
         layer 0's node linear, the two-row edge-input table (``difusco_prepare``) - as an opaque device buffer to hand to
         ``step(prepared=...)``.  None when the fused path does not apply (the step then computes everything itself)."""
-        if not self._uses_prepared(g):      # (a buffer for a call that would ignore it is never handed out)
-            return None
+        if not force and not self._uses_prepared(g):      # (a buffer for a call that would ignore it is never handed out;
+            return None                                   #  force=True: tests of the C entry under a precision without a fused path)
         pts = points.to(self.device, dtype=torch.float32).contiguous()
         if pts.numel() != 2 * g.n_nodes:
             raise ValueError("points must be [n_nodes, 2]")
@@ -207,7 +229,13 @@ class DenoiseEngine:
         pred = torch.empty((rows, 2) if C == 2 else (rows,), dtype=torch.float32, device=dev) if want_pred else None
         prob = torch.empty(rows, dtype=torch.float32, device=dev) if (want_prob and C == 2) else None
         ws = self._workspace(g)
-        tbias = self._tbias.get((torch.cuda.current_stream(dev).cuda_stream, float(t)))
+        tbias = self._tbias.get(float(t))
+        if tbias is not None:
+            tbias[1].wait_on_current_stream()      # (no-op on the producing stream and after the first wait of this stream)
+            tbias = tbias[0]
+        if prepared is not None and isinstance(prepared, tuple):      # (buffer, _ReadyEvent) from models._prepared
+            prepared[1].wait_on_current_stream()
+            prepared = prepared[0]
         # the Philox key and offset are 63-bit on both backends (the torch op schema carries signed 64-bit ints)
         seed, offset = int(seed) & (2 ** 63 - 1), int(offset) & (2 ** 63 - 1)
         if self.backend == "torch":

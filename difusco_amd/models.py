@@ -132,13 +132,16 @@ class COMetaModel:
         if not self.prepare or points is None:
             return None
         version = 0 if points.is_inference() else points._version
-        # (per HIP stream: the buffer is produced asynchronously on the stream that is current here)
-        key = (id(g), points.data_ptr(), tuple(points.shape), version, torch.cuda.current_stream(self.device).cuda_stream)
+        # (the buffer is produced asynchronously on the stream that is current at the miss: the entry carries an event, and a step on
+        #  another stream waits for it once - engine._ReadyEvent; the key holds no stream handle)
+        key = (id(g), points.data_ptr(), tuple(points.shape), version)
         hit = self._prep_cache.get(key)
         if hit is None:
             if len(self._prep_cache) >= 2:      # a sampling loop reuses ONE entry; each pins 5 N H floats + the graph + the points
                 self._prep_cache.clear()
-            hit = (self.model.prepare(g, points), g, points)      # keep g / points alive: id() and data_ptr() stay unique
+            buf = self.model.prepare(g, points)
+            from .engine import _ReadyEvent
+            hit = ((buf, _ReadyEvent(self.device)) if buf is not None else None, g, points)      # keep g / points alive: id() and data_ptr() stay unique
             self._prep_cache[key] = hit
         return hit[0]
 

@@ -34,7 +34,12 @@ def constant_tables(hidden: int):
         d = torch.arange(n, dtype=torch.float32)
         return 10000 ** (2.0 * torch.div(d, 2, rounding_mode="trunc") / n)
 
-    return {"@time_freqs": freqs, "@dimt_pos": dim_t(half), "@dimt_scalar": dim_t(hidden)}
+    tabs = {"@time_freqs": freqs, "@dimt_pos": dim_t(half), "@dimt_scalar": dim_t(hidden)}
+    # the generated-input kernels take one sincos per (sin, cos) feature pair: entries 2j, 2j+1 of a dim_t table must be equal
+    # (include/difusco_hip.h, DIFUSCO_W_DIMT_SCALAR)
+    for name in ("@dimt_pos", "@dimt_scalar"):
+        assert torch.equal(tabs[name][0::2], tabs[name][1::2]), f"{name}: entries 2j and 2j+1 differ"
+    return tabs
 
 
 _SLAB_ORDER = [0, 2, 1, 3]   # slab position group g holds k group _SLAB_ORDER[g] (middle groups of 4 swapped)

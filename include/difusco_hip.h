@@ -72,7 +72,10 @@ enum {
   DIFUSCO_W_OUT_GN_W, DIFUSCO_W_OUT_GN_B, DIFUSCO_W_OUT_CONV_W, DIFUSCO_W_OUT_CONV_B,
   DIFUSCO_W_TIME_FREQS,  /* [H/2]  exp(-ln(1e4) k/(H/2))                      */
   DIFUSCO_W_DIMT_POS,    /* [H/2]  1e4^(2(k/2)/(H/2))  PositionEmbeddingSine   */
-  DIFUSCO_W_DIMT_SCALAR, /* [H]    1e4^(2(k/2)/H)      ScalarEmbeddingSine(1D) */
+  DIFUSCO_W_DIMT_SCALAR, /* [H]    1e4^(2(k/2)/H)      ScalarEmbeddingSine(1D).  REQUIRED: entries 2j and 2j+1 are EQUAL (the
+                            reference's table, gnn_encoder.py:243): the generated-input kernels (edge_embed.hip, the GEN path of
+                            linear_split.hip) take ONE sincos of x / dim_t[2j] for the (sin, cos) feature pair (2j, 2j+1); a blob
+                            with another table diverges from scalar_embed_kernel.  pack_state_dict() asserts it. */
   DIFUSCO_W_EDGE_EMBED_PLANES, /* bf16 split planes of edge_embed.weight, see below */
   DIFUSCO_W_GLOBAL_COUNT
 };

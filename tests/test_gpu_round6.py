@@ -185,3 +185,63 @@ def test_edge_embed_rejects_bad_arguments(dev):
     assert L.difusco_edge_embed(256, 1, 1, P(x), 0, P(x), None, 64, P(x), None, None) < 0          # fp32: no tiled kernel
     assert L.difusco_edge_embed(256, 1, 1, None, 3, P(x), None, 64, P(x), None, None) < 0
     assert L.difusco_edge_embed(256, 1, 1, P(x), 3, P(x), None, 0, P(x), None, None) == 0          # empty: nothing to do
+
+
+@pytest.mark.parametrize("prep_precision", ["fp32", "bf16x6", "bf16x3"])
+def test_prepared_buffer_is_in_the_fused_domain_whatever_precision_prepared_it(dev, prep_precision):
+    """``difusco_prepare`` under FP32 / BF16X6 used to leave the reference's node rows in the buffer while the fused
+    step reads them in its log2(e) domain with b_C folded in - a C caller mixing the two got wrong gates silently.  The buffer is now
+    in the fused domain whatever precision prepared it: a default-engine step on such a buffer equals the stateless step to the
+    rounding of the node linear."""
+    from difusco_amd import TSPModel
+    from difusco_amd.engine import DenoiseEngine
+    p = O.init_params(256, 3, 2, seed=8)
+    pts, ei = O.tsp_instance(200, 10, seed=3)
+    pts, ei = torch.from_numpy(pts).to(dev), torch.from_numpy(ei).to(dev)
+    g = torch.Generator().manual_seed(4)
+    xt = (torch.randn(ei.shape[1], generator=g) > 0).float().to(dev)
+    u = torch.rand(ei.shape[1], generator=g)
+    m = TSPModel(_args("categorical", 10, L=3), p, device=dev, prepare=False, backend="ctypes")
+    csr = m.prepare_graph(ei, pts.shape[0], points=pts)
+    t, tt = 400, 380
+    base = m.categorical_denoise_step(pts, xt, np.array([t]), dev, ei, target_t=np.array([tt]), uniform=u, return_aux=True)
+    other = DenoiseEngine(p, device=dev, precision=prep_precision, backend="ctypes")
+    buf = other.prepare(csr, pts, force=True)
+    assert buf is not None
+    from difusco_amd import _lib
+    post = np.zeros(8, dtype=np.float32)
+    post[:4] = m.diffusion.posterior_constants(t, tt)
+    post[4] = 1.0
+    out = m.model.step(csr, _lib.TASK_TSP, _lib.CATEGORICAL, xt, float(t), post, points=pts, xt_is_binary=True, rand=u.to(dev),
+                       want_pred=True, want_prob=True, prepared=buf)
+    err = (out[1] - base[1]).abs().max().item()
+    print(f"prepared under {prep_precision}, stepped under fp16x3: logits L_inf vs the stateless step {err:.2e}")
+    assert err < CLASS_TOL
+
+
+def test_cached_state_is_ordered_across_streams(dev):
+    """time-bias rows and the prepared buffer are produced asynchronously on the stream that is current at the miss; a
+    step issued on ANOTHER stream waits for the entry's event (no stream handle in the cache keys).  Same bits as the stateless step."""
+    from difusco_amd import TSPModel
+    p = O.init_params(256, 2, 2, seed=9)
+    pts, ei = O.tsp_instance(300, 12, seed=5)
+    pts, ei = torch.from_numpy(pts).to(dev), torch.from_numpy(ei).to(dev)
+    g = torch.Generator().manual_seed(6)
+    xt = (torch.randn(ei.shape[1], generator=g) > 0).float().to(dev)
+    u = torch.rand(ei.shape[1], generator=g)
+    t, tt = 700, 650
+    ref = TSPModel(_args("categorical", 12, L=2), p, device=dev, prepare=False).categorical_denoise_step(
+        pts, xt, np.array([t]), dev, ei, target_t=np.array([tt]), uniform=u, return_aux=True)
+    m = TSPModel(_args("categorical", 12, L=2), p, device=dev)
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        m.prepare_schedule([t])
+        a = m.categorical_denoise_step(pts, xt, np.array([t]), dev, ei, target_t=np.array([tt]), uniform=u, return_aux=True)      # builds the prepared buffer on sa
+    with torch.cuda.stream(sb):      # no host synchronisation in between: the events order sb behind sa's launches
+        b = m.categorical_denoise_step(pts, xt, np.array([t]), dev, ei, target_t=np.array([tt]), uniform=u, return_aux=True)
+    torch.cuda.synchronize()
+    assert len(m.model._tbias) == 1 and len(m._prep_cache) == 1
+    ev = next(iter(m.model._tbias.values()))[1]
+    assert ev.ordered == {sa.cuda_stream, sb.cuda_stream}
+    assert torch.equal(a[1], ref[1]) and torch.equal(b[1], ref[1]) and torch.equal(a[0], ref[0]) and torch.equal(b[0], ref[0])
