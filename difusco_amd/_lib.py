@@ -7,7 +7,7 @@ from .build import LIB_PATH, PROF_LIB_PATH
 
 FLAG_NO_L0_FOLD, FLAG_NO_TAIL_FOLD, FLAG_CHECK_FINITE = 1, 2, 4      # difusco_step_args.flags
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 TASK_TSP, TASK_MIS = 0, 1
 CATEGORICAL, GAUSSIAN = 0, 1
 RAND_NONE, RAND_INJECTED, RAND_PHILOX = 0, 1, 2
@@ -51,6 +51,7 @@ class StepArgs(ctypes.Structure):
         ("gn_phase", ctypes.c_int32), ("flags", ctypes.c_int32), ("gn_sums", ctypes.c_void_p),
         ("prepared", ctypes.c_void_p), ("tbias", ctypes.c_void_p),      # optional prepared state (ABI 9)
         ("aggregation", ctypes.c_int32), ("reserved0", ctypes.c_int32),   # DIFUSCO_AGG_* (ABI 10)
+        ("gen_table", ctypes.c_void_p),                                     # optional generated-input table (ABI 12)
     ]
 
 
@@ -87,7 +88,10 @@ def lib():
     L.difusco_prepared_bytes.argtypes = [i32, i32]
     L.difusco_prepare.argtypes = [ctypes.POINTER(StepArgs), vp, ctypes.c_size_t]
     L.difusco_time_bias_rows.argtypes = [i32, i32, i32, f32p, ctypes.POINTER(ctypes.c_float), i32, f32p, vp]
-    L.difusco_edge_embed.argtypes = [i32, i32, i32, f32p, i32, f32p, vp, i64, f32p, f32p, vp]
+    L.difusco_edge_embed.argtypes = [i32, i32, i32, f32p, i32, f32p, vp, i64, f32p, f32p, f32p, vp]
+    L.difusco_gen_table_bytes.restype = ctypes.c_size_t
+    L.difusco_gen_table_bytes.argtypes = [i32]
+    L.difusco_gen_table_build.argtypes = [i32, i32, i32, f32p, f32p, ctypes.c_size_t, vp]
     L.difusco_linear_rows.argtypes = [f32p, f32p, f32p, f32p, f32p, i64, i32, i32, i64, vp]
     L.difusco_linear_rows_split.argtypes = [f32p, vp, i32, f32p, f32p, f32p, i64, i32, i32, i64, f32p, vp]
     L.difusco_fused_scratch_bytes.restype = ctypes.c_size_t

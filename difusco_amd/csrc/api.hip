@@ -185,6 +185,10 @@ struct ProfScope {
 
 }  // namespace
 
+#ifdef DIFUSCO_PROFILING
+static int g_step_skip = 0;      // difusco_debug_set key 11 (profiling library): launches of the step that are skipped for an upper-bound timing
+#endif
+
 extern "C" {
 
 int difusco_abi_version(void) { return DIFUSCO_ABI_VERSION; }
@@ -391,7 +395,7 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                    (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0);
         PROF(PROF_EMBED, launch_edge_embed_tiled(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), pl, (long long)H * H, a->precision,
                                                  f16 ? G(DIFUSCO_W_EDGE_EMBED_PLANES) + (long long)5 * H * H / 2 : nullptr,
-                                                 G(DIFUSCO_W_EDGE_EMBED_B), ws.e, E, f16 ? ws.etmax : nullptr, st))
+                                                 G(DIFUSCO_W_EDGE_EMBED_B), ws.e, E, f16 ? ws.etmax : nullptr, st, a->gen_table))
       } else {
         PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
         PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_PLANES),
@@ -419,6 +423,10 @@ int difusco_denoise_step(const difusco_step_args* a) {
     const float* node4 = prep_l ? prep.node4_0 : ws.node4;
     if (prep_l) {
     } else
+#ifdef DIFUSCO_PROFILING
+    if ((g_step_skip & 2) && l >= 2) {      // (timing only, WRONG results: the node linear's launches from layer 2 on are skipped)
+    } else
+#endif
     if (a->precision != DIFUSCO_PREC_FP32 && H == 256) {   // node rows on the same split-precision matrix-core path
       const unsigned short* npl = reinterpret_cast<const unsigned short*>(LW(l, DIFUSCO_WL_NODE4_PLANES)) +
                                   (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * 4 * H * H : 0);
@@ -468,6 +476,9 @@ int difusco_denoise_step(const difusco_step_args* a) {
     }
     if (fused && gn_fold && l == L - 1) continue;     // TSP: h is not read after the last layer
     if (fused) {
+#ifdef DIFUSCO_PROFILING
+      if (g_step_skip & 1) continue;      // (timing only, WRONG results: what any fold of node_finalize could save at most)
+#endif
       PROF(PROF_GATE, launch_node_finalize((int)N, (int)E, a->rowptr, node4, ws.part, ws.direct, ws.h,
                                            LW(l, DIFUSCO_WL_NORM_H_W), LW(l, DIFUSCO_WL_NORM_H_B),
                                            tbias + (size_t)l * H, tsp ? 1 : 0, f16 ? ws.hscale : nullptr, st,
@@ -544,8 +555,32 @@ int difusco_time_bias_rows(int hidden, int n_layers, int out_channels, const flo
 
 // e0 = edge_embed(ScalarEmbeddingSine(x_t)) for a general (Gaussian / non-binary) x_t, by the kernel the fused step uses (edge_embed.hip):
 // exported for the parity tests (partial tiles, permuted inputs, |x_t| up to 6).
+size_t difusco_gen_table_bytes(int hidden) {
+  if (hidden != 256) return 0;
+  // rows | build scratch: the sinusoidal features of the grid, the grid itself
+  return sizeof(float) * ((size_t)2 * difusco::kGenRows * 256 + 1024);
+}
+
+int difusco_gen_table_build(int hidden, int n_layers, int out_channels, const float* weights, float* table, size_t table_bytes,
+                            void* stream) {
+  using namespace difusco;
+  if (hidden != 256) return fail(DIFUSCO_EINVAL, "difusco_gen_table_build: hidden = 256 required");
+  if (n_layers < 1 || (out_channels != 1 && out_channels != 2) || !weights || !table) return fail(DIFUSCO_EINVAL, "bad model shape / null pointer");
+  if (table_bytes < difusco_gen_table_bytes(hidden)) return fail(DIFUSCO_EWORKSPACE, "gen table buffer too small: %zu < %zu", table_bytes, difusco_gen_table_bytes(hidden));
+  const Layout lo = make_layout(hidden, n_layers, out_channels);
+  auto G = [&](int id) { return weights + lo.off[id]; };
+  const int H = hidden;
+  hipStream_t st = (hipStream_t)stream;
+  float* feat = table + (size_t)kGenRows * H;
+  float* grid = feat + (size_t)kGenRows * H;
+  HIP_TRY(launch_gen_table_grid(grid, st));
+  HIP_TRY(launch_scalar_embed(grid, nullptr, G(DIFUSCO_W_DIMT_SCALAR), kGenRows, H, feat, st));       // precise sin / cos of x / dim_t
+  HIP_TRY(linear_rows(feat, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_B), nullptr, table, kGenRows, H, H, H, st));   // exact fp32 MFMA
+  return DIFUSCO_OK;
+}
+
 int difusco_edge_embed(int hidden, int n_layers, int out_channels, const float* weights, int precision, const float* xt,
-                       const int32_t* perm, int64_t n_edges, float* e_tiled, float* tile_max, void* stream) {
+                       const int32_t* perm, int64_t n_edges, float* e_tiled, float* tile_max, const float* gen_table, void* stream) {
   using namespace difusco;
   if (hidden != 256) return fail(DIFUSCO_EINVAL, "difusco_edge_embed: the tiled kernel exists for hidden = 256");
   if (n_layers < 1 || (out_channels != 1 && out_channels != 2)) return fail(DIFUSCO_EINVAL, "n_layers >= 1, out_channels in {1,2} required");
@@ -559,7 +594,7 @@ int difusco_edge_embed(int hidden, int n_layers, int out_channels, const float* 
   const unsigned short* pl = reinterpret_cast<const unsigned short*>(G(DIFUSCO_W_EDGE_EMBED_PLANES)) + (f16 ? (long long)3 * H * H : 0);
   HIP_TRY(launch_edge_embed_tiled(xt, perm, G(DIFUSCO_W_DIMT_SCALAR), pl, (long long)H * H, precision,
                                   f16 ? G(DIFUSCO_W_EDGE_EMBED_PLANES) + (long long)5 * H * H / 2 : nullptr, G(DIFUSCO_W_EDGE_EMBED_B),
-                                  e_tiled, n_edges, tile_max, (hipStream_t)stream));
+                                  e_tiled, n_edges, tile_max, (hipStream_t)stream, gen_table));
   return DIFUSCO_OK;
 }
 
@@ -744,6 +779,7 @@ int difusco_debug_set(int key, int value) {
   if (key == 9) { difusco::g_fused_start_delay = value; return DIFUSCO_OK; }
   if (key == 7) { difusco::g_fused_opt = value; return DIFUSCO_OK; }
   if (key == 10 && value >= 0 && value <= 31) { difusco::g_node_linear_ablate = value; return DIFUSCO_OK; }
+  if (key == 11 && value >= 0 && value <= 3) { g_step_skip = value; return DIFUSCO_OK; }      // bit 0: no node_finalize launches, bit 1: no node linears from layer 2 on
   if (key == 8 && (value == 0 || value == 1 || value == 4)) { difusco::g_node_linear_depth = value; return DIFUSCO_OK; }
   return fail(DIFUSCO_EINVAL, "unknown debug key %d", key);
 }

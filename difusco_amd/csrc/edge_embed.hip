@@ -12,6 +12,17 @@
 // The general row-linear with generated rows (linear_split.hip, GEN) stages both operands through LDS with two barriers per 16-k step:
 // 0.78 ms per launch at E = 10^6; this kernel is what the step driver uses on the fused path (round 5), the general one stays for
 // the unfused sequence.  Arithmetic of the features: that of scalar_embed_kernel / the GEN path (x / dim_t[c], precise sincosf).
+//
+// ROUND 6 - the TABLE path.  e0 is a function of ONE scalar per edge: e0(x) = W_emb [sin(x w_k), cos(x w_k)]_k + b_emb, a smooth curve in
+// R^256 (128 frequencies w_k = 10^(-4k/128) <= 1).  `gen_table` holds that curve sampled on the grid x_r = kGenXMin + (r - 1) / 32
+// (515 rows of 1 KiB, built once per weight blob by difusco_gen_table_build with the EXACT fp32 kernels: scalar_embed_kernel + the
+// fp32-MFMA row linear); a workgroup whose 128 edges all lie in [-8, 8) evaluates e0 by four-point (cubic Lagrange) interpolation of the
+// four neighbouring rows instead of the K = 256 contraction: no sincosf, no MFMA, 16 multiply-adds per float4 - the kernel becomes a
+// pure write stream.  Interpolation error: (3/128) h^4 max|d4 e0 / dx4| with h = 1/32 and sum_k |W_fk| w_k^4 <~ 0.5: ~1e-8, below the
+// fp32 rounding of the rows themselves (~1e-7); the position inside the cell, (x - x_i) * 32, is EXACT in fp32 (grid points are
+// multiples of 2^-5).  Measured against the float64 curve: table path 2e-7, GEMM path (fp16x3) 1e-6 (tests/test_gpu_round6.py).
+// A workgroup with an edge outside the table (|x| >= 8: never reached by x_t of a diffusion run, but the ABI takes any float) or a
+// non-finite x runs the GEMM path below, edge for edge the old kernel.  gen_table == nullptr: always the GEMM path.
 #include "edge_layer_common.h"
 
 namespace difusco {
@@ -28,7 +39,8 @@ __global__ __launch_bounds__(256, 2) void edge_embed_tiled_kernel(const float* _
                                                                   const unsigned short* __restrict__ planes, long long plane_stride,
                                                                   const float* __restrict__ w_inv, const float* __restrict__ bias,
                                                                   float* __restrict__ e, long long n_edges,
-                                                                  float* __restrict__ tile_max) {
+                                                                  float* __restrict__ tile_max,
+                                                                  const float* __restrict__ gen_table) {
   using namespace edge_embed;
   typedef typename T::frag frag;
   // (ONE __shared__ object: the two stage buffers and, behind them, the 256 dim_t values.  dim_t is read from LDS, not from global
@@ -61,6 +73,42 @@ __global__ __launch_bounds__(256, 2) void edge_embed_tiled_kernel(const float* _
           dvoff, (t) * 8192 + pl * plane_bytes + i * 1024, 0, 0);                                                    \
   }
   const float xv = x[perm ? perm[s] : s];
+  if (gen_table != nullptr) {      // ---- TABLE path (see the header): taken by a workgroup whose edges all lie inside the table
+    const float u = (xv - kGenXMin) * kGenInvH;
+    const bool inside = u >= 0.0f && u < (float)kGenIntervals;      // (false for NaN)
+    if (__syncthreads_and(inside || !valid)) {
+      int ci = (int)u;      // cell: rows ci .. ci + 3 hold the grid points x_c - h, x_c, x_c + h, x_c + 2h with x_c = kGenXMin + ci h
+      ci = ci < 0 ? 0 : (ci > kGenIntervals - 1 ? kGenIntervals - 1 : ci);      // (pad lanes only)
+      const float sp = (xv - (kGenXMin + (float)ci * kGenH)) * kGenInvH;      // position in the cell, exact (Sterbenz; powers of two)
+      // cubic Lagrange weights of the nodes -1, 0, 1, 2
+      const float sm1 = sp - 1.0f, sm2 = sp - 2.0f, sp1 = sp + 1.0f;
+      const float w0 = -(1.0f / 6.0f) * sp * sm1 * sm2, w1 = 0.5f * sp1 * sm1 * sm2, w2 = -0.5f * sp1 * sp * sm2,
+                  w3 = (1.0f / 6.0f) * sp1 * sp * sm1;
+      const float* r0 = gen_table + (long long)ci * H + 4 * hh;
+      float* const etile = e + tile * (32 * H);
+      float tmx = 0.0f;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int f = 32 * nb + 8 * g;
+          const v4f a0 = *reinterpret_cast<const v4f*>(r0 + f), a1 = *reinterpret_cast<const v4f*>(r0 + H + f),
+                    a2 = *reinterpret_cast<const v4f*>(r0 + 2 * H + f), a3 = *reinterpret_cast<const v4f*>(r0 + 3 * H + f);
+          const v4f v = (a0 * w0 + a3 * w3) + (a1 * w1 + a2 * w2);      // (small outer terms first)
+          if (valid) {
+            *reinterpret_cast<v4f*>(etile + (2 * nb + (g >> 1)) * 512 + (g & 1) * 256 + lane * 4) = v;
+            tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+            tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+          }
+        }
+      if (tile_max != nullptr) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tmx = __builtin_fmaxf(tmx, __shfl_xor(tmx, off, 64));
+        if (lane == 0) tile_max[tile] = tmx;
+      }
+      return;
+    }
+  }
   dimt_s[tid] = dimt[tid];      // (256 threads, 256 features; visible after the barrier below)
   EMBED_DMA_STAGE(0)
 
@@ -152,19 +200,31 @@ __global__ __launch_bounds__(256, 2) void edge_embed_tiled_kernel(const float* _
 }
 
 // mode: 1 = bf16 planes (unscaled), 3 = fp16 planes (w_inv required).  planes: first plane of that type, [16 slabs][256 rows][16];
-// e: tiled [ceil(n_edges / 256) * 256, 256]; tile_max: one float per 32-edge tile of the padded range, or null.
+// e: tiled [ceil(n_edges / 256) * 256, 256]; tile_max: one float per 32-edge tile of the padded range, or null; gen_table: the rows of
+// difusco_gen_table_build (table path for the workgroups inside its range), or null.
 hipError_t launch_edge_embed_tiled(const float* x, const int* perm, const float* dimt, const unsigned short* planes, long long plane_stride,
                                    int mode, const float* w_inv, const float* bias, float* e, long long n_edges, float* tile_max,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, const float* gen_table) {
   if (n_edges <= 0) return hipSuccess;
   if ((mode != 1 && mode != 3) || (mode == 3 && w_inv == nullptr)) return hipErrorInvalidValue;
   const unsigned grid = (unsigned)((n_edges + 127) / 128);
   if (mode == 3)
     hipLaunchKernelGGL((edge_embed_tiled_kernel<FFp16>), dim3(grid), dim3(256), 0, stream, x, perm, dimt, planes, plane_stride, w_inv, bias, e,
-                       n_edges, tile_max);
+                       n_edges, tile_max, gen_table);
   else
     hipLaunchKernelGGL((edge_embed_tiled_kernel<FBf16>), dim3(grid), dim3(256), 0, stream, x, perm, dimt, planes, plane_stride, nullptr, bias, e,
-                       n_edges, tile_max);
+                       n_edges, tile_max, gen_table);
+  return hipGetLastError();
+}
+
+// x[r] = kGenXMin + (r - 1) h, r < kGenRows: the sample points of the table (exact: multiples of 2^-5)
+__global__ void gen_table_grid_kernel(float* __restrict__ x) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < kGenRows) x[r] = kGenXMin + (float)(r - 1) * kGenH;
+}
+
+hipError_t launch_gen_table_grid(float* x, hipStream_t stream) {
+  hipLaunchKernelGGL(gen_table_grid_kernel, dim3((kGenRows + 255) / 256), dim3(256), 0, stream, x);
   return hipGetLastError();
 }
 

@@ -77,7 +77,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
     const c10::optional<at::Tensor>& points, const at::Tensor& xt, double t, c10::ArrayRef<double> post,
     const c10::optional<at::Tensor>& rand, int64_t seed, int64_t offset, at::Tensor workspace, c10::ArrayRef<int64_t> cfg,
     bool want_pred, bool want_prob, const c10::optional<at::Tensor>& gn_sums, const c10::optional<at::Tensor>& prepared,
-    const c10::optional<at::Tensor>& tbias) {
+    const c10::optional<at::Tensor>& tbias, const c10::optional<at::Tensor>& gen_table) {
   TORCH_CHECK(cfg.size() == 9 || cfg.size() == 10,
               "cfg = {hidden, n_layers, out_channels, task, precision, no_fusion, xt_is_binary, gn_phase, flags[, aggregation]}");
   TORCH_CHECK(post.size() <= 8, "post holds at most 8 constants");
@@ -141,6 +141,12 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> step_impl(
     need(*tbias, at::kFloat, "tbias", true);
     TORCH_CHECK(tbias->numel() == cfg[0] * cfg[1], "tbias must be [n_layers, hidden]");
   }
+  a.gen_table = static_cast<const float*>(ptr_or_null(gen_table));      // optional generated-input table (ABI 12)
+  if (a.gen_table) {
+    need(*gen_table, at::kFloat, "gen_table", true);
+    TORCH_CHECK((size_t)gen_table->nbytes() >= difusco_gen_table_bytes((int)cfg[0]) && difusco_gen_table_bytes((int)cfg[0]) > 0,
+                "gen_table: the buffer of gen_table_build() required");
+  }
   if (a.prepared)
     TORCH_CHECK(prepared->is_cuda() && prepared->is_contiguous() &&
                     (size_t)prepared->nbytes() >= difusco_prepared_bytes((int)cfg[0], (int)n_nodes),
@@ -196,16 +202,31 @@ at::Tensor time_bias_rows(const at::Tensor& weights, c10::ArrayRef<double> times
   return out;
 }
 
+// The generated-input table of a weight blob (include/difusco_hip.h, ABI 12): float32 buffer of difusco_gen_table_bytes().
+at::Tensor gen_table_build(const at::Tensor& weights, c10::ArrayRef<int64_t> cfg) {
+  TORCH_CHECK(cfg.size() >= 3, "cfg = {hidden, n_layers, out_channels, ...}");
+  need(weights, at::kFloat, "weights", true);
+  const c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(weights.device());
+  const size_t bytes = difusco_gen_table_bytes((int)cfg[0]);
+  TORCH_CHECK(bytes > 0, "difusco_gen_table_bytes rejected the shape (hidden = 256 required)");
+  at::Tensor out = at::empty({(int64_t)(bytes / sizeof(float))}, weights.options());
+  check(difusco_gen_table_build((int)cfg[0], (int)cfg[1], (int)cfg[2], weights.data_ptr<float>(), out.data_ptr<float>(), bytes,
+                                (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(weights.device().index()).stream()),
+        "difusco_gen_table_build");
+  return out;
+}
+
 #define STEP_SIGNATURE                                                                                                   \
   const at::Tensor &weights, const at::Tensor &rowptr, const at::Tensor &col, const c10::optional<at::Tensor>&perm,     \
       const c10::optional<at::Tensor>&row, const c10::optional<at::Tensor>&seg_ptr,                                     \
       const c10::optional<at::Tensor>&points, const at::Tensor &xt, double t, c10::ArrayRef<double> post,               \
       const c10::optional<at::Tensor>&rand, int64_t seed, int64_t offset, at::Tensor workspace,                         \
       c10::ArrayRef<int64_t> cfg, bool want_pred, bool want_prob, const c10::optional<at::Tensor>&gn_sums,             \
-      const c10::optional<at::Tensor>&prepared, const c10::optional<at::Tensor>&tbias
+      const c10::optional<at::Tensor>&prepared, const c10::optional<at::Tensor>&tbias,                                  \
+      const c10::optional<at::Tensor>&gen_table
 #define STEP_FORWARD                                                                                                     \
   weights, rowptr, col, perm, row, seg_ptr, points, xt, t, post, rand, seed, offset, workspace, cfg, want_pred, want_prob, \
-      gn_sums, prepared, tbias
+      gn_sums, prepared, tbias, gen_table
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> denoise_step_categorical(STEP_SIGNATURE) {
   return step_impl(DIFUSCO_CATEGORICAL, STEP_FORWARD);
@@ -217,7 +238,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> denoise_step_gaussian(STEP_SIGNAT
 const char* kStepSchema =
     "(Tensor weights, Tensor rowptr, Tensor col, Tensor? perm, Tensor? row, Tensor? seg_ptr, Tensor? points, Tensor xt, "
     "float t, float[] post, Tensor? rand, int seed, int offset, Tensor(a!) workspace, int[] cfg, bool want_pred, "
-    "bool want_prob, Tensor(b!)? gn_sums, Tensor? prepared=None, Tensor? tbias=None) -> (Tensor, Tensor, Tensor)";
+    "bool want_prob, Tensor(b!)? gn_sums, Tensor? prepared=None, Tensor? tbias=None, Tensor? gen_table=None) -> (Tensor, Tensor, Tensor)";
 
 }  // namespace
 
@@ -228,6 +249,7 @@ TORCH_LIBRARY(difusco, m) {
   m.def("abi_version() -> int", []() -> int64_t { return difusco_abi_version(); });
   m.def("prepare_state(Tensor weights, Tensor points, int n_nodes, int n_edges, int n_segments, Tensor(a!) workspace, int[] cfg) -> Tensor");
   m.def("time_bias_rows(Tensor weights, float[] times, int[] cfg) -> Tensor");
+  m.def("gen_table_build(Tensor weights, int[] cfg) -> Tensor");
   m.def((std::string("denoise_step_categorical") + kStepSchema).c_str());
   m.def((std::string("denoise_step_gaussian") + kStepSchema).c_str());
 }
@@ -238,6 +260,7 @@ TORCH_LIBRARY_IMPL(difusco, CPU, m) { m.impl("prepare_graph", &prepare_graph); }
 TORCH_LIBRARY_IMPL(difusco, CUDA, m) {
   m.impl("prepare_state", &prepare_state);
   m.impl("time_bias_rows", &time_bias_rows);
+  m.impl("gen_table_build", &gen_table_build);
   m.impl("denoise_step_categorical", &denoise_step_categorical);
   m.impl("denoise_step_gaussian", &denoise_step_gaussian);
 }

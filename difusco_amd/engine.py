@@ -49,12 +49,14 @@ class _ReadyEvent:
 
 class DenoiseEngine:
     def __init__(self, state_dict=None, device="cuda:0", blob: Optional[torch.Tensor] = None, precision: str = "fp16x3",
-                 fused: bool = True, backend: Optional[str] = None, flags: int = 0, config=None, aggregation: str = "sum"):
+                 fused: bool = True, backend: Optional[str] = None, flags: int = 0, config=None, aggregation: str = "sum",
+                 use_gen_table: bool = True):
         """state_dict: reference GNNEncoder weights (optionally with the Lightning ``model.`` prefix).
         ``blob`` + ``config=(hidden, n_layers, out_channels)``: an already packed blob (e.g. received by RCCL broadcast)
         instead of a state_dict to pack here.  ``aggregation``: the reference's ``--aggregation`` (``train.py:52``,
         ``gnn_encoder.py:170-191``): "sum" (every published run), "mean" or "max"."""
         self.device = torch.device(device)
+        self.use_gen_table = bool(use_gen_table)      # False: general edge inputs always take the K = 256 contraction (A/B, parity tests)
         if self.device.type != "cuda":
             raise _lib.DifuscoHipError("DenoiseEngine needs a GPU device (no CPU fallback exists)")
         _lib.lib()  # fail loudly, now, if the HIP library is missing
@@ -102,6 +104,7 @@ class DenoiseEngine:
                     "use backend='ctypes' with the profiling library / DIFUSCO_HIP_LIBRARY")
             self._ops = torch_ops.load()
         self._ws = {}               # HIP stream -> workspace tensor
+        self._gen_table = None      # (table, _ReadyEvent): the generated-input table of this blob (difusco_gen_table_build), built on first use
         self._tbias = {}            # t -> ([n_layers, hidden] time-bias rows on the device, _ReadyEvent) (prepare_times)
         self.calls = 0
 
@@ -124,6 +127,27 @@ class DenoiseEngine:
         aggregation}"""
         return [self.hidden, self.n_layers, self.out_channels, task, _lib.PRECISIONS[self.precision], 0 if self.fused else 1,
                 1 if xt_is_binary else 0, phase, self.flags, _lib.AGGREGATIONS[self.aggregation]]
+
+    # ---- generated-input table (difusco_step_args.gen_table, ABI 12) --------------------------------
+    def gen_table(self) -> Optional[torch.Tensor]:
+        """The table that lets a TSP step with a general edge input (Gaussian diffusion, non-binary categorical x_t) evaluate
+        ``edge_embed(ScalarEmbeddingSine(x_t))`` (``gnn_encoder.py:230-249,304,395``) by interpolation for |x_t| < 8 - a function of the
+        weights only, built once per engine on the fused path (H = 256); None otherwise or when ``use_gen_table`` is False."""
+        if not self.use_gen_table or not (self.fused and self.hidden == 256 and self.precision in ("bf16x3", "fp16x3")):
+            return None
+        if self._gen_table is None:
+            if self.backend == "torch":
+                tab = _op_call(self._ops.gen_table_build, self.blob, self._cfg())
+            else:
+                need = _lib.lib().difusco_gen_table_bytes(self.hidden)
+                tab = torch.empty(need // 4, dtype=torch.float32, device=self.device)
+                with torch.cuda.device(self.device):
+                    _lib.check(_lib.lib().difusco_gen_table_build(
+                        self.hidden, self.n_layers, self.out_channels, _ptr(self.blob), _ptr(tab), need,
+                        ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            self._gen_table = (tab, _ReadyEvent(self.device))
+        self._gen_table[1].wait_on_current_stream()
+        return self._gen_table[0]
 
     # ---- prepared state (difusco_step_args.prepared / .tbias) --------------------------------------
     def prepare_times(self, ts) -> None:
@@ -236,11 +260,12 @@ class DenoiseEngine:
         if prepared is not None and isinstance(prepared, tuple):      # (buffer, _ReadyEvent) from models._prepared
             prepared[1].wait_on_current_stream()
             prepared = prepared[0]
+        gen_table = self.gen_table() if (task == _lib.TASK_TSP and not xt_is_binary) else None
         # the Philox key and offset are 63-bit on both backends (the torch op schema carries signed 64-bit ints)
         seed, offset = int(seed) & (2 ** 63 - 1), int(offset) & (2 ** 63 - 1)
         if self.backend == "torch":
             return self._step_torch_op(g, task, diffusion, xt, t, post, points, xt_is_binary, rand, seed, offset,
-                                       want_pred, want_prob, gn_reduce, ws, prepared, tbias)
+                                       want_pred, want_prob, gn_reduce, ws, prepared, tbias, gen_table)
 
         a = _lib.StepArgs()
         a.struct_size = ctypes.sizeof(_lib.StepArgs)
@@ -268,6 +293,7 @@ class DenoiseEngine:
         a.gn_phase, a.gn_sums = 0, None
         a.flags = self.flags
         a.prepared, a.tbias = _ptr(prepared), _ptr(tbias)
+        a.gen_table = _ptr(gen_table)
         a.aggregation = _lib.AGGREGATIONS[self.aggregation]
         with torch.cuda.device(dev):
             if gn_reduce is None:
@@ -286,7 +312,7 @@ class DenoiseEngine:
         return xt_out, pred, prob
 
     def _step_torch_op(self, g, task, diffusion, xt, t, post, points, xt_is_binary, rand, seed, offset, want_pred,
-                       want_prob, gn_reduce, ws, prepared=None, tbias=None):
+                       want_prob, gn_reduce, ws, prepared=None, tbias=None, gen_table=None):
         """The same step through ``torch.ops.difusco.denoise_step_{categorical,gaussian}`` (csrc/torch_ops.cpp)."""
         op = self._ops.denoise_step_categorical if diffusion == _lib.CATEGORICAL else self._ops.denoise_step_gaussian
         cfg = self._cfg(task, xt_is_binary)
@@ -296,7 +322,7 @@ class DenoiseEngine:
         def call(phase, sums):
             cfg[7] = phase
             return _op_call(op, self.blob, g.rowptr, g.col, g.perm, g.row, seg, points, xt, float(t), post, rand, seed, offset, ws,
-                            cfg, want_pred, want_prob, sums, prepared, tbias)
+                            cfg, want_pred, want_prob, sums, prepared, tbias, gen_table)
         if gn_reduce is None:
             out = call(0, None)
         else:

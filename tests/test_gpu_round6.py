@@ -126,16 +126,30 @@ def test_default_engine_on_trained_like_weights(dev, step, weights_kind):
             assert (out_x.cpu().reshape(-1) - ref_x.reshape(-1)).abs().max().item() < CLASS_TOL
 
 
-@pytest.mark.parametrize("precision,bound", [("fp16x3", CLASS_TOL), ("bf16x3", TOL)])
+def _gen_table(blob, H, Lyr, C, dev):
+    from difusco_amd import _lib
+    L = _lib.lib()
+    need = L.difusco_gen_table_bytes(H)
+    assert need >= 515 * 256 * 4
+    tab = torch.empty(need // 4, dtype=torch.float32, device=dev)
+    _lib.check(L.difusco_gen_table_build(H, Lyr, C, ctypes.c_void_p(blob.data_ptr()), ctypes.c_void_p(tab.data_ptr()), need,
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return tab
+
+
+@pytest.mark.parametrize("path,precision,bound", [("gemm", "fp16x3", CLASS_TOL), ("gemm", "bf16x3", TOL), ("table", "fp16x3", 1e-6)])
 @pytest.mark.parametrize("E", [31, 33, 127, 129, 4099])
-def test_edge_embed_kernel_partial_tiles_permuted(dev, E, precision, bound):
+def test_edge_embed_kernel_partial_tiles_permuted(dev, E, path, precision, bound):
     """``difusco_edge_embed``: e0 = edge_embed(ScalarEmbeddingSine(x_t)) on E edges that do not fill a tile / a workgroup, inputs
     reached through a non-identity permutation, |x_t| up to 6 (Gaussian x_t lives in about +-5); the rows past E stay untouched and
-    the per-tile maxima equal the maxima of what was written."""
+    the per-tile maxima equal the maxima of what was written.  ``gemm``: the K = 256 contraction on generated sinusoid planes;
+    ``table`` (round 6): cubic interpolation in the table of difusco_gen_table_build - held to 1e-6 against the fp32 oracle and to
+    3e-7 against the float64 curve (it is closer to the exact value than the split-precision contraction)."""
     from difusco_amd import _lib, graph, weights
     H, Lyr, C = 256, 1, 1
     p = O.init_params(H, Lyr, C, seed=123)
     blob = weights.pack_state_dict(p).to(dev)
+    tab = _gen_table(blob, H, Lyr, C, dev) if path == "table" else None
     g = torch.Generator().manual_seed(E)
     x_slot = (torch.rand(E, generator=g) * 12.0 - 6.0)
     x_slot[0], x_slot[-1] = 6.0, -6.0
@@ -143,19 +157,24 @@ def test_edge_embed_kernel_partial_tiles_permuted(dev, E, precision, bound):
     x_caller = torch.empty(E)
     x_caller[perm.long()] = x_slot
     ref = O._lin(p, "edge_embed", O.scalar_embedding_sine(x_slot, H))
+    truth = O._lin({k: v.double() for k, v in p.items()}, "edge_embed", O.scalar_embedding_sine(x_slot.double(), H))
     E_pad = (E + 255) // 256 * 256
     e_t = torch.full((E_pad * H,), 7.0, device=dev)
     tmax = torch.full((E_pad // 32,), -1.0, device=dev)
     L = _lib.lib()
-    P = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
     xc, pm = x_caller.to(dev), perm.to(dev)
-    _lib.check(L.difusco_edge_embed(H, Lyr, C, P(blob), _lib.PRECISIONS[precision], P(xc), P(pm), E, P(e_t), P(tmax),
+    _lib.check(L.difusco_edge_embed(H, Lyr, C, P(blob), _lib.PRECISIONS[precision], P(xc), P(pm), E, P(e_t), P(tmax), P(tab),
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     got = graph.from_tiled(e_t, E).cpu()
     err = (got - ref).abs().max().item()
-    print(f"edge_embed {precision} E={E}: L_inf {err:.2e} (|e0| max {ref.abs().max().item():.2f})")
+    err64 = (got.double() - truth).abs().max().item()
+    print(f"edge_embed {path} {precision} E={E}: L_inf vs fp32 oracle {err:.2e}, vs float64 {err64:.2e} (oracle vs float64 "
+          f"{(ref.double() - truth).abs().max().item():.2e}; |e0| max {ref.abs().max().item():.2f})")
     assert err < bound, err
+    if path == "table":
+        assert err64 < 3e-7, err64
     # rows past E: never written
     off = graph.edge_tiled_offsets(E_pad).to(dev)
     if E_pad > E:
@@ -170,10 +189,50 @@ def test_edge_embed_kernel_partial_tiles_permuted(dev, E, precision, bound):
     # identity permutation given as NULL: same bits
     e_t2 = torch.zeros_like(e_t)
     xs = x_slot.to(dev)
-    _lib.check(L.difusco_edge_embed(H, Lyr, C, P(blob), _lib.PRECISIONS[precision], P(xs), None, E, P(e_t2), None,
+    _lib.check(L.difusco_edge_embed(H, Lyr, C, P(blob), _lib.PRECISIONS[precision], P(xs), None, E, P(e_t2), None, P(tab),
                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     assert torch.equal(graph.from_tiled(e_t2, E).cpu(), got)
+
+
+def test_edge_embed_table_range_and_fallback(dev):
+    """The table covers -8 <= x < 8; a workgroup (128 edges) with ANY edge outside it - or a non-finite x - runs the contraction for
+    all of its edges, the others interpolate: every finite row stays at the 1e-5 class, rows of cells at the table's two ends
+    (x = -8, x just below 8) included; a NaN input gives a NaN row on either path (as in the reference: sin(nan))."""
+    from difusco_amd import _lib, graph, weights
+    H, Lyr, C = 256, 1, 1
+    p = O.init_params(H, Lyr, C, seed=124)
+    blob = weights.pack_state_dict(p).to(dev)
+    tab = _gen_table(blob, H, Lyr, C, dev)
+    E = 128 * 5
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(E, generator=g) * 16.0 - 8.0                     # workgroups 0, 1: inside
+    x[0], x[1], x[2], x[3] = -8.0, 7.99, 0.0, float(np.float32(-1e-30))
+    x[2 * 128 + 5] = 8.0                                            # workgroup 2: one edge AT the upper end (outside)
+    x[2 * 128 + 6] = float(np.nextafter(np.float32(8.0), np.float32(0.0)))      # (x + 8 rounds to 16: also outside - either path is right)
+    x[3 * 128 + 77] = -30.0                                         # workgroup 3: far outside
+    x[4 * 128 + 1] = float("nan")                                   # workgroup 4: a NaN
+    ref = O._lin(p, "edge_embed", O.scalar_embedding_sine(x, H))
+    E_pad = (E + 255) // 256 * 256
+    e_t = torch.zeros(E_pad * H, device=dev)
+    L = _lib.lib()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    xd = x.to(dev)
+    _lib.check(L.difusco_edge_embed(H, Lyr, C, P(blob), _lib.PRECISIONS["fp16x3"], P(xd), None, E, P(e_t), None, P(tab),
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = graph.from_tiled(e_t, E).cpu()
+    fin = torch.isfinite(x)
+    err = (got[fin] - ref[fin]).abs().max().item()
+    print(f"edge_embed table + fallback: L_inf {err:.2e} over {int(fin.sum())} finite rows; inside workgroups {(got[:256] - ref[:256]).abs().max().item():.2e}")
+    assert err < CLASS_TOL and (got[:256] - ref[:256]).abs().max().item() < 1e-6
+    assert bool(torch.isnan(got[4 * 128 + 1]).all())
+    # table values themselves: rows r hold e0 at x = -8 + (r - 1) / 32, exact fp32 arithmetic
+    R = 515
+    rows = tab[:R * H].reshape(R, H).cpu()
+    xs = -8.0 + (torch.arange(R, dtype=torch.float32) - 1.0) / 32.0
+    want = O._lin(p, "edge_embed", O.scalar_embedding_sine(xs, H))
+    assert (rows - want).abs().max().item() < 2e-6
 
 
 def test_edge_embed_rejects_bad_arguments(dev):
@@ -181,10 +240,12 @@ def test_edge_embed_rejects_bad_arguments(dev):
     L = _lib.lib()
     x = torch.zeros(64, device=dev)
     P = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
-    assert L.difusco_edge_embed(128, 1, 1, P(x), 3, P(x), None, 64, P(x), None, None) < 0          # hidden != 256
-    assert L.difusco_edge_embed(256, 1, 1, P(x), 0, P(x), None, 64, P(x), None, None) < 0          # fp32: no tiled kernel
-    assert L.difusco_edge_embed(256, 1, 1, None, 3, P(x), None, 64, P(x), None, None) < 0
-    assert L.difusco_edge_embed(256, 1, 1, P(x), 3, P(x), None, 0, P(x), None, None) == 0          # empty: nothing to do
+    assert L.difusco_edge_embed(128, 1, 1, P(x), 3, P(x), None, 64, P(x), None, None, None) < 0          # hidden != 256
+    assert L.difusco_edge_embed(256, 1, 1, P(x), 0, P(x), None, 64, P(x), None, None, None) < 0          # fp32: no tiled kernel
+    assert L.difusco_edge_embed(256, 1, 1, None, 3, P(x), None, 64, P(x), None, None, None) < 0
+    assert L.difusco_edge_embed(256, 1, 1, P(x), 3, P(x), None, 0, P(x), None, None, None) == 0          # empty: nothing to do
+    assert L.difusco_gen_table_bytes(128) == 0 and L.difusco_gen_table_build(128, 1, 1, P(x), P(x), 1 << 22, None) < 0
+    assert L.difusco_gen_table_build(256, 1, 1, P(x), P(x), 16, None) < 0                                # buffer too small
 
 
 @pytest.mark.parametrize("prep_precision", ["fp32", "bf16x6", "bf16x3"])
