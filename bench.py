@@ -48,7 +48,7 @@ def pmc_traffic_bytes(kernel_name, workload, n_edges, variant):
     profiles/r03/pmc_traffic.json (this round's kernel), then profiles/r02/pmc_traffic.json, are keyed by
     "<workload>:<edges on rank 0>:<variant>", i.e. by the exact run the counters were collected on; a run with no profile
     of its own reports None (never another workload's bytes)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
         try:
             table = json.load(open(path))
@@ -81,7 +81,7 @@ def pmc_pipe_busy(workload, n_edges, variant, avg_launch_s, n_simd=1024, clock_h
     run key, profiles/r04/pmc_sq.json; averaged over the launches of a step) / (SIMDs x live average launch time x the
     2.4 GHz the peak is quoted at).  None when that run was never profiled."""
     entry, rnd = None, None
-    for rnd in ("r05", "r04"):      # the newest round that profiled this run key
+    for rnd in ("r06", "r05", "r04"):      # the newest round that profiled this run key
         try:
             entry = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_sq.json"))).get(f"{workload}:{n_edges}:{variant}")
         except (OSError, ValueError):

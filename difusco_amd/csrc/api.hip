@@ -395,7 +395,8 @@ int difusco_denoise_step(const difusco_step_args* a) {
                                    (a->precision == DIFUSCO_PREC_FP16X3 ? (long long)3 * H * H : 0);
         PROF(PROF_EMBED, launch_edge_embed_tiled(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), pl, (long long)H * H, a->precision,
                                                  f16 ? G(DIFUSCO_W_EDGE_EMBED_PLANES) + (long long)5 * H * H / 2 : nullptr,
-                                                 G(DIFUSCO_W_EDGE_EMBED_B), ws.e, E, f16 ? ws.etmax : nullptr, st, a->gen_table))
+                                                 G(DIFUSCO_W_EDGE_EMBED_B), ws.e, E, f16 ? ws.etmax : nullptr, st, a->gen_table,
+                                                 a->gen_table ? reinterpret_cast<int*>(ws.escale) : nullptr))      // (escale: unfused path only - free here)
       } else {
         PROF(PROF_EMBED, launch_scalar_embed(a->xt, a->perm, G(DIFUSCO_W_DIMT_SCALAR), E, H, ws.tmp, st))
         PROF(PROF_LINEAR_EDGE, edge_linear(ws.tmp, G(DIFUSCO_W_EDGE_EMBED_W), G(DIFUSCO_W_EDGE_EMBED_PLANES),
@@ -592,9 +593,13 @@ int difusco_edge_embed(int hidden, int n_layers, int out_channels, const float* 
   const int H = hidden;
   const bool f16 = precision == DIFUSCO_PREC_FP16X3;
   const unsigned short* pl = reinterpret_cast<const unsigned short*>(G(DIFUSCO_W_EDGE_EMBED_PLANES)) + (f16 ? (long long)3 * H * H : 0);
+  // (stand-alone entry: the tile flags live in the table buffer's build scratch - enough for 581,632 edges; the step uses its workspace)
+  int* flags = gen_table ? reinterpret_cast<int*>(const_cast<float*>(gen_table) + (size_t)kGenRows * H) : nullptr;
+  if (gen_table && (n_edges + 127) / 128 * 4 > (int64_t)kGenRows * H)
+    return fail(DIFUSCO_EINVAL, "difusco_edge_embed with a table: at most %d edges per call (use the step for larger inputs)", kGenRows * H * 32);
   HIP_TRY(launch_edge_embed_tiled(xt, perm, G(DIFUSCO_W_DIMT_SCALAR), pl, (long long)H * H, precision,
                                   f16 ? G(DIFUSCO_W_EDGE_EMBED_PLANES) + (long long)5 * H * H / 2 : nullptr, G(DIFUSCO_W_EDGE_EMBED_B),
-                                  e_tiled, n_edges, tile_max, (hipStream_t)stream, gen_table));
+                                  e_tiled, n_edges, tile_max, (hipStream_t)stream, gen_table, flags));
   return DIFUSCO_OK;
 }
 

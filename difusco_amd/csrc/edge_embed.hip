@@ -13,16 +13,15 @@
 // 0.78 ms per launch at E = 10^6; this kernel is what the step driver uses on the fused path (round 5), the general one stays for
 // the unfused sequence.  Arithmetic of the features: that of scalar_embed_kernel / the GEN path (x / dim_t[c], precise sincosf).
 //
-// ROUND 6 - the TABLE path.  e0 is a function of ONE scalar per edge: e0(x) = W_emb [sin(x w_k), cos(x w_k)]_k + b_emb, a smooth curve in
-// R^256 (128 frequencies w_k = 10^(-4k/128) <= 1).  `gen_table` holds that curve sampled on the grid x_r = kGenXMin + (r - 1) / 32
-// (515 rows of 1 KiB, built once per weight blob by difusco_gen_table_build with the EXACT fp32 kernels: scalar_embed_kernel + the
-// fp32-MFMA row linear); a workgroup whose 128 edges all lie in [-8, 8) evaluates e0 by four-point (cubic Lagrange) interpolation of the
-// four neighbouring rows instead of the K = 256 contraction: no sincosf, no MFMA, 16 multiply-adds per float4 - the kernel becomes a
-// pure write stream.  Interpolation error: (3/128) h^4 max|d4 e0 / dx4| with h = 1/32 and sum_k |W_fk| w_k^4 <~ 0.5: ~1e-8, below the
-// fp32 rounding of the rows themselves (~1e-7); the position inside the cell, (x - x_i) * 32, is EXACT in fp32 (grid points are
-// multiples of 2^-5).  Measured against the float64 curve: table path 2e-7, GEMM path (fp16x3) 1e-6 (tests/test_gpu_round6.py).
-// A workgroup with an edge outside the table (|x| >= 8: never reached by x_t of a diffusion run, but the ABI takes any float) or a
-// non-finite x runs the GEMM path below, edge for edge the old kernel.  gen_table == nullptr: always the GEMM path.
+// ROUND 6 - the TABLE kernel (edge_embed_table_kernel below).  e0 is a function of ONE scalar per edge: e0(x) = W_emb [sin(x w_k),
+// cos(x w_k)]_k + b_emb, a smooth curve in R^256 (128 frequencies w_k = 10^(-4k/128) <= 1).  `gen_table` holds that curve sampled at
+// x_r = kGenXMin + (r - 3) / 4 (71 rows of 1 KiB, built once per weight blob by difusco_gen_table_build with the EXACT fp32 kernels:
+// scalar_embed_kernel + the fp32-MFMA row linear).  A 32-edge tile whose edges all lie in [-8, 8) is evaluated by EIGHT-point (degree 7)
+// Lagrange interpolation of the rows around each edge: no sincosf, no MFMA.  Interpolation error on this grid: 2.3e-9 (measured against
+// float64 rows, scratch check in tests/test_gpu_round6.py), far below the fp32 rounding of the rows themselves (1.3e-6: the reference's own
+// fp32 distance from float64 is 1.7e-6); the position inside the cell, (x - x_i) * 4, is EXACT in fp32 (grid points are multiples of 2^-2).
+// A tile with an edge outside the table (|x| >= 8: never reached by x_t of a diffusion run, but the ABI takes any float) or a non-finite x
+// is FLAGGED and left to the contraction kernel, which then runs only the workgroups that hold a flagged tile.
 #include "edge_layer_common.h"
 
 namespace difusco {
@@ -40,7 +39,7 @@ __global__ __launch_bounds__(256, 2) void edge_embed_tiled_kernel(const float* _
                                                                   const float* __restrict__ w_inv, const float* __restrict__ bias,
                                                                   float* __restrict__ e, long long n_edges,
                                                                   float* __restrict__ tile_max,
-                                                                  const float* __restrict__ gen_table) {
+                                                                  const int* __restrict__ tile_flag) {
   using namespace edge_embed;
   typedef typename T::frag frag;
   // (ONE __shared__ object: the two stage buffers and, behind them, the 256 dim_t values.  dim_t is read from LDS, not from global
@@ -72,43 +71,12 @@ __global__ __launch_bounds__(256, 2) void edge_embed_tiled_kernel(const float* _
           (__attribute__((address_space(3))) void*)(wbuf + ((t) & 1) * BUF + pl * PLANE + (2 * wave + i) * 512), 16, \
           dvoff, (t) * 8192 + pl * plane_bytes + i * 1024, 0, 0);                                                    \
   }
-  const float xv = x[perm ? perm[s] : s];
-  if (gen_table != nullptr) {      // ---- TABLE path (see the header): taken by a workgroup whose edges all lie inside the table
-    const float u = (xv - kGenXMin) * kGenInvH;
-    const bool inside = u >= 0.0f && u < (float)kGenIntervals;      // (false for NaN)
-    if (__syncthreads_and(inside || !valid)) {
-      int ci = (int)u;      // cell: rows ci .. ci + 3 hold the grid points x_c - h, x_c, x_c + h, x_c + 2h with x_c = kGenXMin + ci h
-      ci = ci < 0 ? 0 : (ci > kGenIntervals - 1 ? kGenIntervals - 1 : ci);      // (pad lanes only)
-      const float sp = (xv - (kGenXMin + (float)ci * kGenH)) * kGenInvH;      // position in the cell, exact (Sterbenz; powers of two)
-      // cubic Lagrange weights of the nodes -1, 0, 1, 2
-      const float sm1 = sp - 1.0f, sm2 = sp - 2.0f, sp1 = sp + 1.0f;
-      const float w0 = -(1.0f / 6.0f) * sp * sm1 * sm2, w1 = 0.5f * sp1 * sm1 * sm2, w2 = -0.5f * sp1 * sp * sm2,
-                  w3 = (1.0f / 6.0f) * sp1 * sp * sm1;
-      const float* r0 = gen_table + (long long)ci * H + 4 * hh;
-      float* const etile = e + tile * (32 * H);
-      float tmx = 0.0f;
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int f = 32 * nb + 8 * g;
-          const v4f a0 = *reinterpret_cast<const v4f*>(r0 + f), a1 = *reinterpret_cast<const v4f*>(r0 + H + f),
-                    a2 = *reinterpret_cast<const v4f*>(r0 + 2 * H + f), a3 = *reinterpret_cast<const v4f*>(r0 + 3 * H + f);
-          const v4f v = (a0 * w0 + a3 * w3) + (a1 * w1 + a2 * w2);      // (small outer terms first)
-          if (valid) {
-            *reinterpret_cast<v4f*>(etile + (2 * nb + (g >> 1)) * 512 + (g & 1) * 256 + lane * 4) = v;
-            tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
-            tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
-          }
-        }
-      if (tile_max != nullptr) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) tmx = __builtin_fmaxf(tmx, __shfl_xor(tmx, off, 64));
-        if (lane == 0) tile_max[tile] = tmx;
-      }
-      return;
-    }
+  // tile_flag (round 6): the table kernel has already written every tile it could; it flagged the others.  A workgroup runs when one
+  // of its four tiles is flagged (it then recomputes all four: the weight-stage barriers are workgroup wide).
+  if (tile_flag != nullptr) {
+    if (!__syncthreads_or(tile_flag[tile] != 0)) return;
   }
+  const float xv = x[perm ? perm[s] : s];
   dimt_s[tid] = dimt[tid];      // (256 threads, 256 features; visible after the barrier below)
   EMBED_DMA_STAGE(0)
 
@@ -199,28 +167,151 @@ __global__ __launch_bounds__(256, 2) void edge_embed_tiled_kernel(const float* _
   }
 }
 
+// ---- the table kernel ---------------------------------------------------------------------------------------------------------
+// One persistent workgroup of 8 waves per CU; LDS = the 71 table rows (71 KiB) + a transpose buffer of 8 edges x 1 KiB per wave.
+// A wave takes a 32-edge tile: lanes 0..31 hold the edges' cell index and their eight Lagrange weights; for each edge (its index and
+// weights broadcast by v_readlane) lane L accumulates the features 4 L .. 4 L + 3 from the eight rows - all lanes read the SAME row at
+// consecutive 16-byte slots: conflict free, one KiB per ds_read_b128 - and eight edges at a time go through the transpose buffer (row
+// pitch 66 slots: both directions conflict free) so that a store instruction writes eight full 128-byte lines of the tiled layout.
+namespace gen {
+constexpr int NPT = 8, WAVES = 8;
+constexpr int TAB_FLOATS = kGenRows * 256;
+constexpr int PITCH = 66 * 4;                         // floats per staged edge row
+constexpr int LDS_BYTES = (TAB_FLOATS + WAVES * 8 * PITCH) * 4;
+}  // namespace gen
+
+__global__ __launch_bounds__(512, 1) void edge_embed_table_kernel(const float* __restrict__ x, const int* __restrict__ perm,
+                                                                  const float* __restrict__ table, float* __restrict__ e,
+                                                                  long long n_edges, float* __restrict__ tile_max,
+                                                                  int* __restrict__ tile_flag) {
+  using namespace gen;
+  extern __shared__ __attribute__((aligned(16))) float smem_gen[];
+  float* const tab = smem_gen;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const stage = smem_gen + TAB_FLOATS + wave * (8 * PITCH);
+  for (int i = tid; i < TAB_FLOATS / 4; i += 512)
+    *reinterpret_cast<v4f*>(tab + 4 * i) = *reinterpret_cast<const v4f*>(table + 4 * i);
+  __syncthreads();
+  const long long n_tiles = (n_edges + 31) / 32, n_tiles_pad = (n_edges + 127) / 128 * 4;      // (pad tiles of the last 128-edge group report max 0)
+  for (long long tile = (long long)blockIdx.x * WAVES + wave; tile < n_tiles_pad; tile += (long long)gridDim.x * WAVES) {
+    if (tile >= n_tiles) {
+      if (lane == 0 && tile_max != nullptr) tile_max[tile] = 0.0f;
+      continue;
+    }
+    const long long s_raw = tile * 32 + l31;
+    const bool valid = s_raw < n_edges;
+    const long long s = valid ? s_raw : n_edges - 1;
+    const float xv = x[perm ? perm[s] : s];
+    const float u = (xv - kGenXMin) * kGenInvH;
+    const bool inside = u >= 0.0f && u < (float)kGenIntervals;      // (false for NaN)
+    if (__ballot(!inside) != 0ull) {      // (wave uniform) leave the tile to the contraction kernel
+      if (lane == 0) tile_flag[tile] = 1;
+      continue;
+    }
+    int ci = (int)u;      // cell: rows ci .. ci + 7 hold the grid points x_c - 3h .. x_c + 4h, x_c = kGenXMin + ci h
+    const float sp = (xv - (kGenXMin + (float)ci * kGenH)) * kGenInvH;      // position in the cell, exact (Sterbenz; powers of two)
+    // Lagrange weights of the nodes -3 .. 4 at sp: w_a = prod_{b != a} (sp - b) / (a - b)
+    float w[NPT];
+    {
+      const float d[NPT] = {sp + 3.0f, sp + 2.0f, sp + 1.0f, sp, sp - 1.0f, sp - 2.0f, sp - 3.0f, sp - 4.0f};
+      // 1 / prod_{b != a} (a - b) for a = -3 .. 4:  -1/5040, 1/720, -1/240, 1/144, -1/144, 1/240, -1/720, 1/5040
+      constexpr float c[NPT] = {-1.0f / 5040.0f, 1.0f / 720.0f, -1.0f / 240.0f, 1.0f / 144.0f, -1.0f / 144.0f, 1.0f / 240.0f, -1.0f / 720.0f, 1.0f / 5040.0f};
+#pragma unroll
+      for (int a = 0; a < NPT; ++a) {
+        float pr = c[a];
+#pragma unroll
+        for (int b = 0; b < NPT; ++b)
+          if (b != a) pr *= d[b];
+        w[a] = pr;
+      }
+    }
+    float* const etile = e + tile * (32 * 256);
+    float tmx = 0.0f;
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+#pragma unroll
+      for (int ed = 0; ed < 8; ++ed) {
+        const int edge = 8 * grp + ed;
+        const int row = __builtin_amdgcn_readlane(ci, edge);
+        const float* r = tab + row * 256 + lane * 4;
+        // smallest weights first: the outer nodes, then inwards (|w| grows towards the cell)
+        constexpr int order[NPT] = {0, 7, 1, 6, 2, 5, 3, 4};
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int jj = 0; jj < NPT; ++jj) {
+          const int j = order[jj];
+          const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[j]), edge));
+          acc += *reinterpret_cast<const v4f*>(r + j * 256) * wj;
+        }
+        *reinterpret_cast<v4f*>(stage + ed * PITCH + lane * 4) = acc;
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {      // lane L: edge 8 grp + (L & 7), feature quad Q = 8 j + (L >> 3)
+        const int q = 8 * j + (lane >> 3), sidx = 8 * grp + (lane & 7);
+        const v4f v = *reinterpret_cast<const v4f*>(stage + (lane & 7) * PITCH + q * 4);
+        if (tile * 32 + sidx < n_edges) {
+          __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(etile + (q >> 2) * 512 + ((q >> 1) & 1) * 256 + ((q & 1) * 32 + sidx) * 4));
+          tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+          tmx = __builtin_fmaxf(__builtin_fmaxf(tmx, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (tile_max != nullptr) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) tmx = __builtin_fmaxf(tmx, __shfl_xor(tmx, off, 64));
+      if (lane == 0) tile_max[tile] = tmx;
+    }
+  }
+}
+
 // mode: 1 = bf16 planes (unscaled), 3 = fp16 planes (w_inv required).  planes: first plane of that type, [16 slabs][256 rows][16];
-// e: tiled [ceil(n_edges / 256) * 256, 256]; tile_max: one float per 32-edge tile of the padded range, or null; gen_table: the rows of
-// difusco_gen_table_build (table path for the workgroups inside its range), or null.
+// e: tiled [ceil(n_edges / 256) * 256, 256]; tile_max: one float per 32-edge tile of the padded range, or null.
+// gen_table + tile_flag (both or neither; tile_flag: ceil(n_edges / 128) * 4 ints of scratch): the table kernel writes every tile whose
+// edges lie inside the table, flags the others, and the contraction kernel then runs only the workgroups with a flagged tile.
 hipError_t launch_edge_embed_tiled(const float* x, const int* perm, const float* dimt, const unsigned short* planes, long long plane_stride,
                                    int mode, const float* w_inv, const float* bias, float* e, long long n_edges, float* tile_max,
-                                   hipStream_t stream, const float* gen_table) {
+                                   hipStream_t stream, const float* gen_table, int* tile_flag) {
   if (n_edges <= 0) return hipSuccess;
-  if ((mode != 1 && mode != 3) || (mode == 3 && w_inv == nullptr)) return hipErrorInvalidValue;
+  if ((mode != 1 && mode != 3) || (mode == 3 && w_inv == nullptr) || ((gen_table == nullptr) != (tile_flag == nullptr))) return hipErrorInvalidValue;
   const unsigned grid = (unsigned)((n_edges + 127) / 128);
+  if (gen_table != nullptr) {
+    static std::atomic<unsigned long long> attr_devices{0};
+    hipError_t er = ensure_max_dynamic_lds(attr_devices, reinterpret_cast<const void*>(&edge_embed_table_kernel), 160 * 1024);
+    if (er != hipSuccess) return er;
+    er = hipMemsetAsync(tile_flag, 0, sizeof(int) * (size_t)grid * 4, stream);
+    if (er != hipSuccess) return er;
+    static std::atomic<int> n_cu{0};
+    int cus = n_cu.load(std::memory_order_relaxed);
+    if (cus == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+      n_cu.store(cus, std::memory_order_relaxed);
+    }
+    const long long n_tiles_pad = (long long)grid * 4;
+    unsigned tgrid = (unsigned)((n_tiles_pad + gen::WAVES - 1) / gen::WAVES);
+    if (tgrid > (unsigned)cus) tgrid = (unsigned)cus;
+    hipLaunchKernelGGL(edge_embed_table_kernel, dim3(tgrid), dim3(512), gen::LDS_BYTES, stream, x, perm, gen_table, e, n_edges, tile_max, tile_flag);
+    er = hipGetLastError();
+    if (er != hipSuccess) return er;
+  }
   if (mode == 3)
     hipLaunchKernelGGL((edge_embed_tiled_kernel<FFp16>), dim3(grid), dim3(256), 0, stream, x, perm, dimt, planes, plane_stride, w_inv, bias, e,
-                       n_edges, tile_max, gen_table);
+                       n_edges, tile_max, tile_flag);
   else
     hipLaunchKernelGGL((edge_embed_tiled_kernel<FBf16>), dim3(grid), dim3(256), 0, stream, x, perm, dimt, planes, plane_stride, nullptr, bias, e,
-                       n_edges, tile_max, gen_table);
+                       n_edges, tile_max, tile_flag);
   return hipGetLastError();
 }
 
-// x[r] = kGenXMin + (r - 1) h, r < kGenRows: the sample points of the table (exact: multiples of 2^-5)
+// x[r] = kGenXMin + (r - 3) h, r < kGenRows: the sample points of the table (exact: multiples of 2^-2)
 __global__ void gen_table_grid_kernel(float* __restrict__ x) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < kGenRows) x[r] = kGenXMin + (float)(r - 1) * kGenH;
+  if (r < kGenRows) x[r] = kGenXMin + (float)(r - 3) * kGenH;
 }
 
 hipError_t launch_gen_table_grid(float* x, hipStream_t stream) {

@@ -65,11 +65,11 @@ hipError_t linear_scalar_embed_split(const float* x, const int* perm, const floa
 // the fused edge kernel's GEMM 1 (weights streamed through LDS by LDS-DMA, the generated rows as the register-resident MFMA operand)
 hipError_t launch_edge_embed_tiled(const float* x, const int* perm, const float* dimt, const unsigned short* planes, long long plane_stride,
                                    int mode, const float* w_inv, const float* bias, float* e, long long n_edges, float* tile_max,
-                                   hipStream_t stream, const float* gen_table = nullptr);
-// The generated-input table (round 6, edge_embed.hip): e0(x) = edge_embed(ScalarEmbeddingSine(x)) sampled at x_r = kGenXMin + (r - 1) kGenH,
-// r < kGenRows; cell c = floor((x - kGenXMin) / kGenH) in [0, kGenIntervals) interpolates rows c .. c + 3.
-constexpr float kGenXMin = -8.0f, kGenH = 1.0f / 32.0f, kGenInvH = 32.0f;
-constexpr int kGenIntervals = 512, kGenRows = kGenIntervals + 3;
+                                   hipStream_t stream, const float* gen_table = nullptr, int* tile_flag = nullptr);
+// The generated-input table (round 6, edge_embed.hip): e0(x) = edge_embed(ScalarEmbeddingSine(x)) sampled at x_r = kGenXMin + (r - 3) kGenH,
+// r < kGenRows; cell c = floor((x - kGenXMin) / kGenH) in [0, kGenIntervals) interpolates rows c .. c + 7 (degree-7 Lagrange).
+constexpr float kGenXMin = -8.0f, kGenH = 0.25f, kGenInvH = 4.0f;
+constexpr int kGenIntervals = 64, kGenRows = kGenIntervals + 7;
 hipError_t launch_gen_table_grid(float* x, hipStream_t stream);
 
 // scale[r] = power-of-two operand scale of row r of x[m][k] (fp16 split path)

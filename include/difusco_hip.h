@@ -219,9 +219,10 @@ typedef struct difusco_step_args {
   /* ABI 12.  Optional GENERATED-INPUT TABLE (TSP, fused path, hidden 256): the buffer difusco_gen_table_build() filled for THESE weights.
    * A step whose edge input is not a two-row lookup (Gaussian diffusion; a categorical x_t that is not exactly {0,1}) computes
    * e0 = edge_embed(ScalarEmbeddingSine(x_t)) (gnn_encoder.py:230-249,:304,:395): a function of ONE scalar per edge.  With the table,
-   * workgroups whose 128 edges all have -8 <= x_t < 8 evaluate it by cubic interpolation of four sampled rows (error ~1e-8, below the
-   * fp32 rounding of the contraction it replaces; csrc/edge_embed.hip) instead of 64 sincos + a K = 256 contraction per edge; edges
-   * outside the table, non-finite x_t and NULL take the contraction.  Results differ from the table-free step by fp32 rounding only. */
+   * every 32-edge tile whose x_t all lie in [-8, 8) is evaluated by degree-7 interpolation of eight sampled rows (interpolation error
+   * 2e-9, far below the fp32 rounding of the contraction it replaces; csrc/edge_embed.hip) instead of 64 sincos + a K = 256 contraction
+   * per edge; tiles with an edge outside the table or a non-finite x_t, and NULL, take the contraction.  Results differ from the
+   * table-free step by fp32 rounding only. */
   const float* gen_table;
 } difusco_step_args;
 
@@ -253,11 +254,12 @@ int difusco_time_bias_rows(int hidden, int n_layers, int out_channels, const flo
  * exported for parity tests.  hidden = 256; precision = DIFUSCO_PREC_BF16X3 | _FP16X3.  xt [n_edges] in caller order, perm (or
  * NULL) maps CSR slot -> caller index; e_tiled: the TILED edge state (layout at difusco_edge_layer_fused below), padded to a multiple of 256 rows
  * (only the n_edges real rows are written); tile_max (or NULL): one float per 32-edge tile of the padded range = max |e0| of the
- * tile (0 for tiles past the end); gen_table (or NULL): the table of difusco_gen_table_build - workgroups inside its range interpolate. */
+ * tile (0 for tiles past the end); gen_table (or NULL): the table of difusco_gen_table_build - tiles inside its range interpolate
+ * (stand-alone entry: at most 581,632 edges per call with a table; the tile flags live in the table buffer's scratch). */
 int difusco_edge_embed(int hidden, int n_layers, int out_channels, const float* weights, int precision, const float* xt,
                        const int32_t* perm, int64_t n_edges, float* e_tiled, float* tile_max, const float* gen_table, void* stream);
 
-/* The generated-input table of difusco_step_args.gen_table (ABI 12): 515 rows of e0(x) at x = -8 - 1/32 + r / 32, computed with the exact
+/* The generated-input table of difusco_step_args.gen_table (ABI 12): 71 rows of e0(x) at x = -8 + (r - 3) / 4, computed with the exact
  * fp32 kernels (precise sin / cos features, fp32-MFMA linear) from the blob's edge_embed weights; depends on the weights only - build once
  * per blob.  difusco_gen_table_bytes(): size of the buffer (rows + build scratch); hidden must be 256.  Asynchronous on the stream. */
 size_t difusco_gen_table_bytes(int hidden);

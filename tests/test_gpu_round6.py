@@ -130,21 +130,22 @@ def _gen_table(blob, H, Lyr, C, dev):
     from difusco_amd import _lib
     L = _lib.lib()
     need = L.difusco_gen_table_bytes(H)
-    assert need >= 515 * 256 * 4
+    assert need >= 71 * 256 * 4
     tab = torch.empty(need // 4, dtype=torch.float32, device=dev)
     _lib.check(L.difusco_gen_table_build(H, Lyr, C, ctypes.c_void_p(blob.data_ptr()), ctypes.c_void_p(tab.data_ptr()), need,
                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return tab
 
 
-@pytest.mark.parametrize("path,precision,bound", [("gemm", "fp16x3", CLASS_TOL), ("gemm", "bf16x3", TOL), ("table", "fp16x3", 1e-6)])
+@pytest.mark.parametrize("path,precision,bound", [("gemm", "fp16x3", CLASS_TOL), ("gemm", "bf16x3", TOL), ("table", "fp16x3", 3e-6)])
 @pytest.mark.parametrize("E", [31, 33, 127, 129, 4099])
 def test_edge_embed_kernel_partial_tiles_permuted(dev, E, path, precision, bound):
     """``difusco_edge_embed``: e0 = edge_embed(ScalarEmbeddingSine(x_t)) on E edges that do not fill a tile / a workgroup, inputs
     reached through a non-identity permutation, |x_t| up to 6 (Gaussian x_t lives in about +-5); the rows past E stay untouched and
     the per-tile maxima equal the maxima of what was written.  ``gemm``: the K = 256 contraction on generated sinusoid planes;
-    ``table`` (round 6): cubic interpolation in the table of difusco_gen_table_build - held to 1e-6 against the fp32 oracle and to
-    3e-7 against the float64 curve (it is closer to the exact value than the split-precision contraction)."""
+    ``table`` (round 6): degree-7 interpolation in the table of difusco_gen_table_build (LDS-resident, edge_embed_table_kernel) - held
+    to 3e-6 against the fp32 oracle and, against the float64 curve, to the fp32 oracle's OWN distance from it (~1.7e-6: the rounding of
+    x / dim_t and of the fp32 contraction; the interpolation itself contributes 2e-9)."""
     from difusco_amd import _lib, graph, weights
     H, Lyr, C = 256, 1, 1
     p = O.init_params(H, Lyr, C, seed=123)
@@ -174,7 +175,7 @@ def test_edge_embed_kernel_partial_tiles_permuted(dev, E, path, precision, bound
           f"{(ref.double() - truth).abs().max().item():.2e}; |e0| max {ref.abs().max().item():.2f})")
     assert err < bound, err
     if path == "table":
-        assert err64 < 3e-7, err64
+        assert err64 < 1.25 * (ref.double() - truth).abs().max().item() + 2e-7, err64
     # rows past E: never written
     off = graph.edge_tiled_offsets(E_pad).to(dev)
     if E_pad > E:
@@ -196,9 +197,10 @@ def test_edge_embed_kernel_partial_tiles_permuted(dev, E, path, precision, bound
 
 
 def test_edge_embed_table_range_and_fallback(dev):
-    """The table covers -8 <= x < 8; a workgroup (128 edges) with ANY edge outside it - or a non-finite x - runs the contraction for
-    all of its edges, the others interpolate: every finite row stays at the 1e-5 class, rows of cells at the table's two ends
-    (x = -8, x just below 8) included; a NaN input gives a NaN row on either path (as in the reference: sin(nan))."""
+    """The table covers -8 <= x < 8; a 32-edge tile with ANY edge outside it - or a non-finite x - is flagged by the table kernel and
+    computed by the contraction kernel (which recomputes the 128-edge workgroup around it), the other tiles interpolate: every finite
+    row stays at the 1e-5 class, rows of cells at the table's two ends (x = -8, x just below 8) included; a NaN input gives a NaN row
+    (as in the reference: sin(nan))."""
     from difusco_amd import _lib, graph, weights
     H, Lyr, C = 256, 1, 1
     p = O.init_params(H, Lyr, C, seed=124)
@@ -225,12 +227,12 @@ def test_edge_embed_table_range_and_fallback(dev):
     fin = torch.isfinite(x)
     err = (got[fin] - ref[fin]).abs().max().item()
     print(f"edge_embed table + fallback: L_inf {err:.2e} over {int(fin.sum())} finite rows; inside workgroups {(got[:256] - ref[:256]).abs().max().item():.2e}")
-    assert err < CLASS_TOL and (got[:256] - ref[:256]).abs().max().item() < 1e-6
+    assert err < CLASS_TOL and (got[:256] - ref[:256]).abs().max().item() < 3e-6
     assert bool(torch.isnan(got[4 * 128 + 1]).all())
-    # table values themselves: rows r hold e0 at x = -8 + (r - 1) / 32, exact fp32 arithmetic
-    R = 515
+    # table values themselves: rows r hold e0 at x = -8 + (r - 3) / 4, exact fp32 arithmetic
+    R = 71
     rows = tab[:R * H].reshape(R, H).cpu()
-    xs = -8.0 + (torch.arange(R, dtype=torch.float32) - 1.0) / 32.0
+    xs = -8.0 + (torch.arange(R, dtype=torch.float32) - 3.0) / 4.0
     want = O._lin(p, "edge_embed", O.scalar_embedding_sine(xs, H))
     assert (rows - want).abs().max().item() < 2e-6
 
