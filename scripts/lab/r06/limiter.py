@@ -145,18 +145,26 @@ else:
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
 
-    def lab_case(name, x):
+    def lab_case(name, x, variant=142020):
         e_t = graph.to_tiled(x.to(dev))
         out = torch.zeros_like(e_t)
 
         def body():
             for _ in range(200):
-                _lib.check(L.difusco_lab_gemm1_nopk(142020, P(e_t), P(fp16_planes), P(out), E, inv_c, 0, 0, stream))
+                _lib.check(L.difusco_lab_gemm1_nopk(variant, P(e_t), P(fp16_planes), P(out), E, inv_c, 0, 0, stream))
         rec = run_case(name, body, 200, "launches/s")
         rec["mfma_TF_issued"] = 2.0 * E * H * H * 3 * rec["rate"] / 1e12
-        print(f"    -> {1e3 / rec['rate']:.4f} ms per launch, {rec['mfma_TF_issued']:.0f} TF issued = {rec['mfma_TF_issued'] / 2500:.3f} of 2.5 PF", flush=True)
+        rec["J_per_launch"] = (rec["smu"].get("residency", {}).get("avg_power_W_from_energy") or rec["hwmon"].get("power_W_median", 0.0)) / rec["rate"]
+        print(f"    -> {1e3 / rec['rate']:.4f} ms per launch, {rec['J_per_launch']:.4f} J per launch; as fp16x3 work: {rec['mfma_TF_issued']:.0f} TF = "
+              f"{rec['mfma_TF_issued'] / 2500:.3f} of 2.5 PF", flush=True)
 
     lab_case("lab GEMM1 fp16x3 N(0,1) operands", torch.randn(E, H, generator=gen))
     lab_case("lab GEMM1 fp16x3 zero operands", torch.zeros(E, H))
     lab_case("lab GEMM1 fp16x3 N(0,1) again", torch.randn(E, H, generator=gen))
+    # hi.hi in fp16 + both correction products as one FP8 MFMA (K = 64) per two slabs - TIMING / POWER ONLY (stage_lab.hip,
+    # VMIX 4: the operand bytes are those of the fp16 fragments, the result is not the product)
+    xr = torch.randn(E, H, generator=gen)
+    lab_case("lab GEMM1 fp16 + fp8 corrections", xr, 4142020)
+    lab_case("lab GEMM1 fp16x3 (same data)", xr, 142020)
+    lab_case("lab GEMM1 fp16 + fp8 corrections", xr, 4142020)
 print(json.dumps({"mode": MODE, "device": pr.name, "bdf": bdf, "cases": records}))
