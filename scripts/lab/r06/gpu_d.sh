@@ -15,19 +15,19 @@ done
 cat $OUT/ab_node_kernels_skipped.txt
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_stats -o bench -- python $REPO/bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-exact-fp32 --no-workloads --repeats 1 --no-power > $REPO/$OUT/prof_stats.log 2> $REPO/$OUT/prof_stats.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_stats_10k -o bench -- python $REPO/bench.py --workload tsp10000 --steps 5 --warmup 2 --cpu-steps 0 --no-exact-fp32 --repeats 1 --no-power > $REPO/$OUT/prof_stats_10k.log 2> $REPO/$OUT/prof_stats_10k.err
+cd $REPO; python scripts/lab/r06/limiter.py lab 5 > $OUT/limiter_lab_fp8.txt 2> $OUT/limiter_lab_fp8.err; grep -v "^{" $OUT/limiter_lab_fp8.txt
 cd $REPO
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 python - <<'PY'
 import csv, glob, json
-for tag, name in (("prof_stats", "rocprofv3_summary_tsp1000_default.txt"), ("prof_stats_10k", "rocprofv3_summary_tsp10000.txt")):
+for tag, name in (("prof_stats", "rocprofv3_summary_tsp1000_default.txt"),):
     for f in glob.glob(f"gpurun_out/r06d/{tag}/**/*kernel_stats.csv", recursive=True):
         rows = list(csv.DictReader(open(f)))
         with open(f"gpurun_out/r06d/{name}", "w") as out:
             for r in rows[:14]:
                 line = f"{r['Name'][:100]:100s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs']) / 1e6:10.3f} avg_us {float(r['AverageNs']) / 1e3:9.2f} pct {r['Percentage']}"
                 print(line); out.write(line + "\n")
-for tag in ("prof_stats", "prof_stats_10k"):
+for tag in ("prof_stats",):
     try:
         o = json.loads(open(f"gpurun_out/r06d/{tag}.log").read().strip().splitlines()[-1])
         print(tag, "profiled run: live avg_launch_ms", o["roofline"]["avg_launch_ms"], "value", o["value"])
