@@ -231,20 +231,29 @@ __global__ __launch_bounds__(512, 1) void edge_embed_table_kernel(const float* _
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
 #pragma unroll
-      for (int ed = 0; ed < 8; ++ed) {
-        const int edge = 8 * grp + ed;
-        const int row = __builtin_amdgcn_readlane(ci, edge);
-        const float* r = tab + row * 256 + lane * 4;
-        // smallest weights first: the outer nodes, then inwards (|w| grows towards the cell)
-        constexpr int order[NPT] = {0, 7, 1, 6, 2, 5, 3, 4};
-        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int ed = 0; ed < 8; ed += 2) {      // two edges per step: their sixteen row reads are issued before the first multiply-add
+        constexpr int order[NPT] = {0, 7, 1, 6, 2, 5, 3, 4};      // smallest weights first: the outer nodes, then inwards
+        v4f rr[2][NPT];
 #pragma unroll
-        for (int jj = 0; jj < NPT; ++jj) {
-          const int j = order[jj];
-          const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[j]), edge));
-          acc += *reinterpret_cast<const v4f*>(r + j * 256) * wj;
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int row = __builtin_amdgcn_readlane(ci, 8 * grp + ed + k2);
+          const float* r = tab + row * 256 + lane * 4;
+#pragma unroll
+          for (int j = 0; j < NPT; ++j) rr[k2][j] = *reinterpret_cast<const v4f*>(r + j * 256);
         }
-        *reinterpret_cast<v4f*>(stage + ed * PITCH + lane * 4) = acc;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int edge = 8 * grp + ed + k2;
+          v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int jj = 0; jj < NPT; ++jj) {
+            const int j = order[jj];
+            const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[j]), edge));
+            acc += rr[k2][j] * wj;
+          }
+          *reinterpret_cast<v4f*>(stage + (ed + k2) * PITCH + lane * 4) = acc;
+        }
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
