@@ -589,6 +589,39 @@ extern "C" int difusco_lab_reread_pass(const float* buf, long long n_floats, int
 }
 #endif
 
+// ROUND 6 probe (scripts/lab/r06/f8_probe.py): ONE wave, one v_mfma_scale_f32_32x32x64_f8f6f4 (both operands E4M3) on caller-supplied
+// register images - a[lane][8 dwords], b[lane][8 dwords], one E8M0 scale byte per lane and operand - and, in the same launch, one
+// v_permlane32_swap of two dwords per lane: the operand / scale / result layouts a split-precision kernel with FP8 correction products
+// would have to be written for.  out: [lane][16] accumulators, then [lane][2] swapped dwords.
+namespace difusco {
+__global__ void lab_f8_probe_kernel(const int* __restrict__ a, const int* __restrict__ b, const int* __restrict__ sa,
+                                    const int* __restrict__ sb, const unsigned* __restrict__ sw, float* __restrict__ out) {
+  typedef int v8i_ __attribute__((ext_vector_type(8)));
+  typedef float v16f_ __attribute__((ext_vector_type(16)));
+  typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x;
+  v8i_ av, bv;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    av[j] = a[lane * 8 + j];
+    bv[j] = b[lane * 8 + j];
+  }
+  v16f_ acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, sa[lane], 0, sb[lane]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[lane * 16 + r] = acc[r];
+  const v2u_ sr = __builtin_amdgcn_permlane32_swap(sw[lane * 2], sw[lane * 2 + 1], false, false);
+  out[64 * 16 + lane * 2] = __builtin_bit_cast(float, sr[0]);
+  out[64 * 16 + lane * 2 + 1] = __builtin_bit_cast(float, sr[1]);
+}
+}  // namespace difusco
+extern "C" int difusco_lab_f8_probe(const int* a, const int* b, const int* sa, const int* sb, const unsigned* sw, float* out, void* stream) {
+  hipLaunchKernelGGL(difusco::lab_f8_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, sa, sb, sw, out);
+  return hipGetLastError() == hipSuccess ? DIFUSCO_OK : DIFUSCO_EHIP;
+}
+
 extern "C" {
 // variant = EPW/32 * 100000 + WAVES * 10000 + NBUF * 1000 + SYNC * 100 + RING * 10 + PRIO; MINB follows from the geometry
 // (64-edge waves and 8-wave workgroups are one workgroup per CU, the production geometry two).  planes: the fp16 hi | lo
