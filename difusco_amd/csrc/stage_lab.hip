@@ -587,7 +587,6 @@ extern "C" int difusco_lab_reread_pass(const float* buf, long long n_floats, int
   else hipLaunchKernelGGL((reread_probe_kernel<0>), dim3(2048), dim3(256), 0, (hipStream_t)stream, buf, n4, sink);
   return hipGetLastError() == hipSuccess ? DIFUSCO_OK : DIFUSCO_EHIP;
 }
-#endif
 
 // ROUND 6 probe (scripts/lab/r06/f8_probe.py): ONE wave, one v_mfma_scale_f32_32x32x64_f8f6f4 (both operands E4M3) on caller-supplied
 // register images - a[lane][8 dwords], b[lane][8 dwords], one E8M0 scale byte per lane and operand - and, in the same launch, one
@@ -621,6 +620,7 @@ extern "C" int difusco_lab_f8_probe(const int* a, const int* b, const int* sa, c
   hipLaunchKernelGGL(difusco::lab_f8_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, sa, sb, sw, out);
   return hipGetLastError() == hipSuccess ? DIFUSCO_OK : DIFUSCO_EHIP;
 }
+#endif
 
 extern "C" {
 // variant = EPW/32 * 100000 + WAVES * 10000 + NBUF * 1000 + SYNC * 100 + RING * 10 + PRIO; MINB follows from the geometry
