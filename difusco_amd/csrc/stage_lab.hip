@@ -594,10 +594,10 @@ extern "C" int difusco_lab_reread_pass(const float* buf, long long n_floats, int
 // would have to be written for.  out: [lane][16] accumulators, then [lane][2] swapped dwords.
 namespace difusco {
 __global__ void lab_f8_probe_kernel(const int* __restrict__ a, const int* __restrict__ b, const int* __restrict__ sa,
-                                    const int* __restrict__ sb, const unsigned* __restrict__ sw, float* __restrict__ out) {
+                                    const int* __restrict__ sb, const unsigned* __restrict__ sw, float* __restrict__ out,
+                                    const float* __restrict__ cin) {
   typedef int v8i_ __attribute__((ext_vector_type(8)));
   typedef float v16f_ __attribute__((ext_vector_type(16)));
-  typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x;
   v8i_ av, bv;
 #pragma unroll
@@ -607,17 +607,27 @@ __global__ void lab_f8_probe_kernel(const int* __restrict__ a, const int* __rest
   }
   v16f_ acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int r = 0; r < 16; ++r) acc[r] = cin != nullptr ? cin[lane * 16 + r] : 0.0f;
   acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 0, 0, 0, sa[lane], 0, sb[lane]);
 #pragma unroll
   for (int r = 0; r < 16; ++r) out[lane * 16 + r] = acc[r];
-  const v2u_ sr = __builtin_amdgcn_permlane32_swap(sw[lane * 2], sw[lane * 2 + 1], false, false);
-  out[64 * 16 + lane * 2] = __builtin_bit_cast(float, sr[0]);
-  out[64 * 16 + lane * 2 + 1] = __builtin_bit_cast(float, sr[1]);
+  // (inline assembly: hipcc 7.2 lowers __builtin_amdgcn_permlane32_swap to the instruction but hands back its first result twice)
+  unsigned p0 = sw[lane * 2], p1 = sw[lane * 2 + 1];
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(p0), "+v"(p1));
+  out[64 * 16 + lane * 2] = __builtin_bit_cast(float, p0);
+  out[64 * 16 + lane * 2 + 1] = __builtin_bit_cast(float, p1);
+  if (lane == 0) {      // v_cvt_scalef32_pk_fp8_f32: is the result E4M3(src / scale) or E4M3(src * scale)?  (100, -3) with scale 256 and 1/16
+    typedef short v2s_ __attribute__((ext_vector_type(2)));
+    v2s_ w = {0, 0};
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, 100.0f, -3.0f, 256.0f, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, 100.0f, -3.0f, 0.0625f, true);
+    out[64 * 16 + 128] = __builtin_bit_cast(float, w);
+  }
 }
 }  // namespace difusco
-extern "C" int difusco_lab_f8_probe(const int* a, const int* b, const int* sa, const int* sb, const unsigned* sw, float* out, void* stream) {
-  hipLaunchKernelGGL(difusco::lab_f8_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, sa, sb, sw, out);
+extern "C" int difusco_lab_f8_probe(const int* a, const int* b, const int* sa, const int* sb, const unsigned* sw, float* out, void* stream,
+                                    const float* cin) {
+  hipLaunchKernelGGL(difusco::lab_f8_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, sa, sb, sw, out, cin);
   return hipGetLastError() == hipSuccess ? DIFUSCO_OK : DIFUSCO_EHIP;
 }
 #endif
