@@ -209,7 +209,8 @@ def smu_sampler(device):
     throttler residency shares (PPT / thermal / VR / HBM / PROCHOT) and, per XCD, the share of the timed loops the engine clock
     sat below the host limit because of power or temperature.  None when the metrics table cannot be read on this box."""
     try:
-        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        if os.path.join(ROOT, "scripts") not in sys.path:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
         from smu_metrics import SmuMetrics, SmuSampler
         pr = torch.cuda.get_device_properties(device)
         m = SmuMetrics(pci_bdf=f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0",

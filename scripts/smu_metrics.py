@@ -27,6 +27,9 @@ def _ok(v, nil):
     return None if v == nil else int(v)
 
 
+_AMDSMI_READY = False      # amdsmi_init() once per process (bench.py builds one SmuMetrics per measured workload)
+
+
 class SmuMetrics:
     """One device's metrics table through libamd_smi (the `amdsmi` Python package of the ROCm image: ctypes structs only, the
     C call releases the GIL).  `available` is False - and `why` says so - when the library, the device or the call is missing;
@@ -38,11 +41,14 @@ class SmuMetrics:
             import amdsmi
             from amdsmi import amdsmi_wrapper as w
             self._w = w
-            try:
-                amdsmi.amdsmi_init()
-            except Exception as exc:      # noqa: BLE001
-                self.why = f"amdsmi_init: {exc}"
-                return
+            global _AMDSMI_READY
+            if not _AMDSMI_READY:
+                try:
+                    amdsmi.amdsmi_init()
+                    _AMDSMI_READY = True
+                except Exception as exc:      # noqa: BLE001
+                    self.why = f"amdsmi_init: {exc}"
+                    return
             handles = amdsmi.amdsmi_get_processor_handles()
             pick = None
             if pci_bdf:
