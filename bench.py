@@ -349,7 +349,7 @@ def compact_record(out, full_path=None):
                                     "parity_linf", "host_enqueue_us_per_step", "prepare_ms_per_sampling_run") if k in out}
     cfg = out.get("config", {})
     keep["config"] = {k: cfg[k] for k in ("workload", "name", "graphs_per_gpu", "global_batch", "nodes", "knn", "nodes_rank0", "edges_rank0",
-                                          "gn_stats", "binding", "edge_linear_arithmetic", "fused_edge_layer", "aggregation") if k in cfg}
+                                          "gn_stats", "binding", "edge_linear_arithmetic", "fused_edge_layer", "aggregation", "gaussian_xt") if k in cfg}
     rep = out.get("repeats")
     if rep:
         keep["repeats"] = {"n": rep["n"], "ms_per_step": _r(rep["ms_per_step"]), "min_ms_per_step": _r(rep["min_ms_per_step"]),
@@ -393,6 +393,8 @@ def compact_record(out, full_path=None):
                                        "hbm_frac": _r(r.get("hbm_frac_of_8TBs")), "avg_launch_ms": _r(r.get("avg_launch_ms")),
                                        "other_ms": _r(r.get("other_ms_per_step")), "parity_linf": _r(w.get("parity_linf")),
                                        "cpu": _r(c.get("value")), "cpu_cores": c.get("cores")}
+            if "gaussian_xt" in w["config"]:      # (Gaussian workloads: which x_t the steps received, --gaussian-xt)
+                keep["workloads"][name]["xt"] = "N(0,1) per step" if w["config"]["gaussian_xt"].startswith("N(0,1)") else "free running"
     keep["full_record"] = os.path.basename(full_path) if full_path else "stderr"
     return keep
 
